@@ -1,0 +1,177 @@
+/* libsbl_hip.so — C ABI of the MI355X-native (gfx950) SBL lip-reading hot path.
+ *
+ * The reference (VIPL SBL_For_Multilingual_Lip_Reading) has no FFI: its boundary is the
+ * Python class surface of SBL_Multilingual_Lip_reading/transformer/ ("SBL/..." below).
+ * Each entry point here replaces the torch ops one reference call site issues; the Python
+ * mirror (sbl_for_multilingual_lip_reading_amd/transformer/) binds them through ctypes
+ * (see INTEGRATION.md for the stub a maintainer adds to the reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked host.
+ *   - the CALLER allocates every output and workspace; nothing is allocated inside.
+ *   - every call only enqueues work on `stream` (hipStream_t passed as void*): no sync, no
+ *     host read-back, so any sequence of calls can be captured into a hipGraph.
+ *   - return 0 on success, otherwise a hipError_t value or SBL_ERR_INVALID (bad shape /
+ *     alignment, checked on the host BEFORE any launch); text via sbl_last_error()
+ *     (thread-local).  No global mutable state: safe from several host threads on distinct
+ *     streams/devices (nn.DataParallel's threading model, SBL/train.py:115).
+ *   - activations of the visual trunk are NHWC ("channels last"): (image, h, w, c), image =
+ *     n*T + t — the reference's transpose/contiguous/view (SBL/transformer/video_frontend.py:113-115)
+ *     is folded into the layout.  Transformer tensors are row-major (B, L, 512).
+ *   - fp32 everywhere (the reference's dtype); matrix products use v_mfma_f32_32x32x2_f32.
+ */
+#ifndef SBL_HIP_H
+#define SBL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBL_ERR_INVALID (-22)
+#define SBL_ABI_VERSION 1
+
+typedef void* sbl_stream_t; /* hipStream_t */
+
+const char* sbl_last_error(void);
+int sbl_abi_version(void);
+
+/* ---------------------------------------------------------------- dense GEMM / Linear
+ * C[M,N] (+)= opA(A)[M,K] * opB(B)[K,N], row-major; opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k],
+ * opB(B)[k,n] = transB ? B[n*ldb+k] : B[k*ldb+n].  Epilogue: +bias[n], ReLU, or multiply by
+ * (relu_mask[m*ldm+n] > 0) (ReLU backward fused into the producing GEMM).
+ * accumulate: 0 = overwrite, 1 = C += (in place).
+ * Replaces nn.Linear forward/backward: SBL/transformer/attention.py:16-18,27,41-43,57;
+ * module.py:42-43,49; encoder.py:27,54; decoder.py:59-60,166-167. */
+int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                 float* C, long ldc, const float* bias, int relu, const float* relu_mask, long ldm, int accumulate,
+                 sbl_stream_t stream);
+/* out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
+int sbl_colsum_f32(const float* X, long ldx, float* out, int M, int N, int accumulate, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- stem (frontend3D)
+ * Conv3d(1,64,(5,7,7),s(1,2,2),p(2,3,3),bias=False) -> BatchNorm3d(64) -> ReLU ->
+ * MaxPool3d((1,3,3),s(1,2,2),p(0,1,1)): SBL/transformer/video_frontend.py:99-104.
+ * x: (N,T,H,W) fp32 (C=1).  conv_out: (N*T,Ho,Wo,64), Ho=H/2, Wo=W/2.  pooled: (N*T,Ho/2,Wo/2,64).
+ * stats: double[128] = per-channel (sum, sumsq) of conv_out; zeroed by the call. */
+int sbl_stem_conv_fwd(const float* x, const float* w /*[64][245]*/, float* conv_out, double* stats, int N, int T, int H,
+                      int W, sbl_stream_t stream);
+int sbl_stem_bn_relu_pool_fwd(const float* conv_out, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* pooled, uint8_t* argmax, int NT, int Ho, int Wo,
+                              sbl_stream_t stream);
+/* backward pass 1: sums = double[128] (sum g, sum g*xhat), g = grad wrt BN output after pool/ReLU adjoints */
+int sbl_stem_bwd_reduce(const float* conv_out, const float* dpooled, const uint8_t* argmax, const float* mean,
+                        const float* invstd, const float* gamma, const float* beta, double* sums, int NT, int Ho,
+                        int Wo, sbl_stream_t stream);
+/* backward pass 2: dconv recomputed on the fly and contracted with the input patches:
+ * dw[64][245] (zeroed by the call), dgamma[64], dbeta[64].  No input gradient (x is data). */
+int sbl_stem_wgrad(const float* x, const float* conv_out, const float* dpooled, const uint8_t* argmax,
+                   const float* mean, const float* invstd, const float* gamma, const float* beta, const double* sums,
+                   float* dw, float* dgamma, float* dbeta, int N, int T, int H, int W, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- BatchNorm (train / eval)
+ * nn.BatchNorm{2,3}d defaults: SBL/transformer/video_frontend.py:21,24,71,101. */
+int sbl_bn_finalize(const double* stats /*[2C]*/, long count, float* running_mean, float* running_var,
+                    float momentum, float eps, float* save_mean, float* save_invstd, int C, sbl_stream_t stream);
+int sbl_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd,
+                      int C, sbl_stream_t stream);
+/* y = [relu]( gamma*(x-mean)*invstd + beta [+ res] ), NHWC rows x C */
+int sbl_bn_apply_fwd(const float* x, const float* res, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, float* y, long rows, int C, int relu, sbl_stream_t stream);
+/* sums = double[2C] (sum g, sum g*xhat), g = dy * (y>0 if relu); zeroed by the call */
+int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      double* sums, long rows, int C, int relu, sbl_stream_t stream);
+/* dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (if non-null); dgamma, dbeta from sums */
+int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, const double* sums, float* dx, float* dres, float* dgamma, float* dbeta,
+                     long rows, int C, int relu, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- ResNet-18 trunk convolutions
+ * conv3x3 / 1x1-stride-2, bias-free, NHWC implicit GEMM: SBL/transformer/video_frontend.py:10-12,69-70.
+ * Weights are used in OHWI order [Cout][KH][KW][Cin]; pack/unpack convert from/to the
+ * reference's OIHW parameter layout (state-dict shapes stay the reference's). */
+int sbl_conv_weight_pack(const float* w_oihw, float* w_ohwi, float* w_dgrad /*[Cin][KH][KW][Cout] or NULL*/, int Cout,
+                         int Cin, int KH, int KW, sbl_stream_t stream);
+int sbl_conv_wgrad_unpack(const float* dw_ohwi, float* dw_oihw, int Cout, int Cin, int KH, int KW,
+                          sbl_stream_t stream);
+/* stats: NULL or double[2*Cout] (sum, sumsq of y) accumulated by the epilogue; zeroed by the call */
+int sbl_conv2d_fwd(const float* x, const float* w_ohwi, float* y, double* stats, int NIMG, int H, int W, int Cin,
+                   int Cout, int KH, int KW, int stride, int pad, sbl_stream_t stream);
+int sbl_conv2d_dgrad(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad, sbl_stream_t stream);
+/* dw_ohwi zeroed by the call, then split-K float atomics */
+int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, int NIMG, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad, sbl_stream_t stream);
+/* AdaptiveAvgPool2d(1): (NIMG,HW,C) -> (NIMG,C): video_frontend.py:53,87-88 */
+int sbl_avgpool_fwd(const float* x, float* y, int NIMG, int HW, int C, sbl_stream_t stream);
+int sbl_avgpool_bwd(const float* dy, float* dx, int NIMG, int HW, int C, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- dropout (fused Philox-style masks)
+ * y = x * keep / (1-p); the mask is a function of (*seed, offset, element index) and is
+ * regenerated in backward.  F.dropout(p=0.5) video_frontend.py:122; nn.Dropout(0.1) x80. */
+int sbl_dropout(const float* x, float* y, long n, float p, const uint64_t* seed, uint64_t offset,
+                sbl_stream_t stream);
+int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- LayerNorm with fused residual
+ * y = LN(x + res) * gamma + beta (eps 1e-5), rows of D=512: attention.py:58, module.py:51, encoder.py:54. */
+int sbl_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                          float* mean, float* rstd, int M, int D, float eps, sbl_stream_t stream);
+/* dz (= dx = dres); dgamma/dbeta accumulated with float atomics (caller zeroes or accumulates) */
+int sbl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
+                          const float* rstd, float* dz, float* dgamma, float* dbeta, int M, int D,
+                          sbl_stream_t stream);
+/* y = x + pe[l] (l = row % L) : encoder.py:53-55 positional add */
+int sbl_add_pe(const float* x, const float* pe, float* y, int B, int L, int D, sbl_stream_t stream);
+
+/* y[m,:] = x[m,:] * s[m]: the `*= non_pad_mask` of encoder.py:86,89 / decoder.py:399,403,406 (ragged lengths) */
+int sbl_rowscale(const float* x, const float* s, float* y, long M, int D, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- scaled dot-product attention
+ * One workgroup per (batch, head): S = Q K^T * scale, mask, softmax over keys, [dropout], O = P V.
+ * q/k/v/o are (B, L, H*64) row-major views with row strides ldq/ldk/ldv/ldo (heads are the
+ * contiguous 64-wide column blocks: attention.py:41-47); p_out is (H*B, Lq, Lk) head-major like
+ * the reference's returned attn.  mask_kind: 0 none, 1 causal (key > query masked:
+ * utils.py:116-124), 2 explicit uint8 (B,Lq,Lk), nonzero = masked.  Lq, Lk <= 64, d = 64.
+ * Replaces attention.py:72-83. */
+int sbl_attention_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o, long ldo,
+                      float* p_out, int mask_kind, const uint8_t* mask, int B, int H, int Lq, int Lk, float scale,
+                      float drop_p, const uint64_t* seed, uint64_t offset, sbl_stream_t stream);
+int sbl_attention_bwd(const float* dout, long lddo, const float* q, long ldq, const float* k, long ldk, const float* v,
+                      long ldv, const float* p, float* dq, long lddq, float* dk, long lddk, float* dv, long lddv,
+                      int B, int H, int Lq, int Lk, float scale, float drop_p, const uint64_t* seed, uint64_t offset,
+                      sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- SBL decoder pieces
+ * out[b,l,:] = emb[tok[b*ldt + l]] + pe[l]: decoder.py:116-120 */
+int sbl_embed_pe_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B, int L, int D,
+                     int V, sbl_stream_t stream);
+/* demb[tok] += dy (float atomics) */
+int sbl_embed_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, int L, int D, int V,
+                  sbl_stream_t stream);
+/* A' = A + flip_t(B), B' = 2B + flip_t(A): closed form of the aliased loops decoder.py:132-143,160-164 */
+int sbl_fusion_fwd(const float* a, const float* b, float* a2, float* b2, int B, int L, int D, sbl_stream_t stream);
+int sbl_fusion_bwd(const float* da2, const float* db2, float* da, float* db, int B, int L, int D,
+                   sbl_stream_t stream);
+/* ys[b, step+1] = use_argmax ? argmax_c pred[b,c] : gold[b, step]: decoder.py:173-186.
+ * use_argmax: host int, or if coins_dev != NULL coins_dev[step] (device int32, for graph replay). */
+int sbl_argmax_select(const float* pred, long ldp, const int64_t* gold, long ldg, int64_t* ys, long ldy, int step,
+                      int use_argmax, const int32_t* coins_dev, int B, int V, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- label-smoothed cross entropy
+ * SBL/transformer/loss.py:27-52.  out[0]=sum of row losses, out[1]=#valid rows, out[2]=#correct
+ * (zeroed by the call).  bwd: dpred = gscale[0] / out[1] * (softmax - q) on valid rows. */
+int sbl_smoothed_ce_fwd(const float* pred, const int64_t* gold, float* out3, int R, int C, float eps, int ignore_id,
+                        sbl_stream_t stream);
+int sbl_smoothed_ce_bwd(const float* pred, const int64_t* gold, const float* out3, const float* gscale, float* dpred,
+                        int R, int C, float eps, int ignore_id, sbl_stream_t stream);
+
+/* ---------------------------------------------------------------- fused Adam
+ * torch.optim.Adam(betas=(0.9,0.98), eps=1e-9) over a flat fp32 buffer, grad pre-scaled by
+ * grad_scale (1/world_size): SBL/train.py:75, SBL/transformer/optimizer.py:18-27. */
+int sbl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  int step, float grad_scale, sbl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,180 @@
+// ResNet-18 trunk convolutions as NHWC implicit GEMM on the fp32 MFMA tile engine
+// (SBL/transformer/video_frontend.py:10-12 conv3x3, :69-70 1x1/stride-2 shortcut).
+//   fwd   : y[pix, co]            = sum_{tap,ci} x[gather(pix,tap), ci] * w[co, tap, ci]      (+ BN stats)
+//   dgrad : dx[pix, ci]           = sum_{tap,co} dy[gather'(pix,tap), co] * wt[ci, tap, co]
+//   wgrad : dw[co, (tap,ci)]      = sum_{pix}    dy[pix, co] * x[gather(pix,tap), ci]         (split-K atomics)
+#include "mfma_gemm.h"
+
+static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    SBL_REQUIRE(NIMG > 0 && H > 0 && W > 0, "%s: bad image dims %d %d %d", who, NIMG, H, W);
+    SBL_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cout >= 16, "%s: Cin=%d Cout=%d must be multiples of 16", who, Cin, Cout);
+    SBL_REQUIRE((KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0), "%s: only 3x3/pad1 and 1x1/pad0 (got %dx%d pad %d)", who, KH, KW, pad);
+    SBL_REQUIRE(stride == 1 || stride == 2, "%s: stride %d", who, stride);
+    SBL_REQUIRE((long)NIMG * H * W * (long)(Cin > Cout ? Cin : Cout) < (1L << 31), "%s: tensor too large for 32-bit pixel index", who);
+    return 0;
+}
+static inline int out_dim(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
+
+extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* stats, int NIMG, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_conv("sbl_conv2d_fwd", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
+    SBL_REQUIRE(x && w && y && sbl_aligned16(x) && sbl_aligned16(w), "sbl_conv2d_fwd: null/unaligned pointer");
+    const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
+    const int M = NIMG * Ho * Wo, N = Cout, K = KH * KW * Cin;
+    ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad};
+    if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
+    const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+#define SBL_CONV_FWD(BM, BN)                                                                                   \
+    do {                                                                                                       \
+        ConvGatherKC<BM, false> al{x, g, M};                                                                   \
+        DenseKC<BN, true> bl{w, (long)K, N};                                                                   \
+        if (stats) {                                                                                           \
+            EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0};                                    \
+            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN>(al, bl, e, M, N, K, 1, s); \
+        } else {                                                                                               \
+            EpiStore<0, false> e{y, (long)N, nullptr, 0, nullptr, nullptr, 0};                                 \
+            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s); \
+        }                                                                                                      \
+    } while (0)
+    if (N >= 128 && t128 >= 512) SBL_CONV_FWD(128, 128);
+    else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_FWD(128, 64);
+    else SBL_CONV_FWD(64, 64);
+#undef SBL_CONV_FWD
+    SBL_LAUNCH_CHECK("sbl_conv2d_fwd");
+    return 0;
+}
+
+extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                                int KH, int KW, int stride, int pad, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_conv("sbl_conv2d_dgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
+    SBL_REQUIRE(dy && wt && dx && sbl_aligned16(dy) && sbl_aligned16(wt), "sbl_conv2d_dgrad: null/unaligned pointer");
+    const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
+    const int M = NIMG * H * W, N = Cin, K = KH * KW * Cout;
+    ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad};
+    const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+#define SBL_CONV_DG(BM, BN)                                                                                   \
+    do {                                                                                                      \
+        ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
+        DenseKC<BN, true> bl{wt, (long)K, N};                                                                 \
+        EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
+        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s); \
+    } while (0)
+    if (N >= 128 && t128 >= 512) SBL_CONV_DG(128, 128);
+    else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_DG(128, 64);
+    else SBL_CONV_DG(64, 64);
+#undef SBL_CONV_DG
+    SBL_LAUNCH_CHECK("sbl_conv2d_dgrad");
+    return 0;
+}
+
+extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int NIMG, int H, int W, int Cin, int Cout,
+                                int KH, int KW, int stride, int pad, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_conv("sbl_conv2d_wgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
+    SBL_REQUIRE(x && dy && dw && sbl_aligned16(x) && sbl_aligned16(dy), "sbl_conv2d_wgrad: null/unaligned pointer");
+    const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
+    const int M = Cout, N = KH * KW * Cin, K = NIMG * Ho * Wo;   // reduce over output pixels
+    ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad};
+    SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * N, s));
+    // split the pixel reduction so that ~1024 workgroups are in flight; chunks stay >= 256 pixels
+    const long tiles = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
+    int splits = (int)((1024 + tiles - 1) / tiles);
+    if (splits > K / 256) splits = K / 256;
+    if (splits < 1) splits = 1;
+    DenseMC<64, true> al{dy, (long)Cout, M};
+    ConvGatherMC<64> bl{x, g, N};
+    EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};
+    sbl_launch_gemm<DenseMC<64, true>, ConvGatherMC<64>, EpiStore<2, false>, 64, 64>(al, bl, e, M, N, K, splits, s);
+    SBL_LAUNCH_CHECK("sbl_conv2d_wgrad");
+    return 0;
+}
+
+// ------------------------------------------------------------------ weight layout
+// OIHW (state-dict layout) -> OHWI [Cout][KH][KW][Cin]  (+ dgrad operand [Cin][KH][KW][Cout])
+__global__ void weight_pack_kernel(const float* __restrict__ w, float* __restrict__ ohwi, float* __restrict__ wt,
+                                   int Cout, int Cin, int KH, int KW) {
+    long n = (long)Cout * Cin * KH * KW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // i indexes OHWI
+        int ci = i % Cin;
+        long t = i / Cin;
+        int kw = t % KW;
+        t /= KW;
+        int kh = t % KH;
+        int co = t / KH;
+        float v = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+        ohwi[i] = v;
+        if (wt) wt[(((long)ci * KH + kh) * KW + kw) * Cout + co] = v;
+    }
+}
+__global__ void wgrad_unpack_kernel(const float* __restrict__ ohwi, float* __restrict__ oihw, int Cout, int Cin, int KH,
+                                    int KW) {
+    long n = (long)Cout * Cin * KH * KW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // i indexes OIHW
+        int kw = i % KW;
+        long t = i / KW;
+        int kh = t % KH;
+        t /= KH;
+        int ci = t % Cin;
+        int co = t / Cin;
+        oihw[i] = ohwi[(((long)co * KH + kh) * KW + kw) * Cin + ci];
+    }
+}
+extern "C" int sbl_conv_weight_pack(const float* w, float* ohwi, float* wt, int Cout, int Cin, int KH, int KW,
+                                    sbl_stream_t stream) {
+    SBL_REQUIRE(w && ohwi && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "sbl_conv_weight_pack: bad args");
+    long n = (long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(weight_pack_kernel, dim3(sbl_cdiv(n, 256) > 2048 ? 2048 : sbl_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, ohwi, wt, Cout, Cin, KH, KW);
+    SBL_LAUNCH_CHECK("sbl_conv_weight_pack");
+    return 0;
+}
+extern "C" int sbl_conv_wgrad_unpack(const float* ohwi, float* oihw, int Cout, int Cin, int KH, int KW,
+                                     sbl_stream_t stream) {
+    SBL_REQUIRE(ohwi && oihw && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "sbl_conv_wgrad_unpack: bad args");
+    long n = (long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(sbl_cdiv(n, 256) > 2048 ? 2048 : sbl_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ohwi, oihw, Cout, Cin, KH, KW);
+    SBL_LAUNCH_CHECK("sbl_conv_wgrad_unpack");
+    return 0;
+}
+
+// ------------------------------------------------------------------ global average pool (NHWC)
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NIMG, int HW, int C) {
+    long n = (long)NIMG * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c = i % C;
+        long img = i / C;
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += x[(img * HW + p) * C + c];
+        y[i] = s / (float)HW;
+    }
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NIMG, int HW, int C) {
+    long n = (long)NIMG * HW * C;
+    const float inv = 1.f / (float)HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c = i % C;
+        long img = i / ((long)HW * C);
+        dx[i] = dy[img * C + c] * inv;
+    }
+}
+extern "C" int sbl_avgpool_fwd(const float* x, float* y, int NIMG, int HW, int C, sbl_stream_t stream) {
+    SBL_REQUIRE(x && y && NIMG > 0 && HW > 0 && C > 0, "sbl_avgpool_fwd: bad args");
+    long n = (long)NIMG * C;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(sbl_cdiv(n, 256) > 4096 ? 4096 : sbl_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, NIMG, HW, C);
+    SBL_LAUNCH_CHECK("sbl_avgpool_fwd");
+    return 0;
+}
+extern "C" int sbl_avgpool_bwd(const float* dy, float* dx, int NIMG, int HW, int C, sbl_stream_t stream) {
+    SBL_REQUIRE(dy && dx && NIMG > 0 && HW > 0 && C > 0, "sbl_avgpool_bwd: bad args");
+    long n = (long)NIMG * HW * C;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(sbl_cdiv(n, 256) > 4096 ? 4096 : sbl_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, NIMG, HW, C);
+    SBL_LAUNCH_CHECK("sbl_avgpool_bwd");
+    return 0;
+}

@@ -1,0 +1,122 @@
+// Dense fp32 GEMM entry points (nn.Linear forward / input-grad / weight-grad, bias grads).
+#include <stdarg.h>
+
+#include "mfma_gemm.h"
+
+// ------------------------------------------------------------------ error text (thread-local)
+static thread_local char g_err[512] = "";
+void sbl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sbl_last_error(void) { return g_err; }
+extern "C" int sbl_abi_version(void) { return SBL_ABI_VERSION; }
+
+// ------------------------------------------------------------------ dispatch
+template <class AL, class BL, int BM, int BN>
+static void launch_mode(const AL& al, const BL& bl, float* C, long ldc, const float* bias, int relu,
+                        const float* relu_mask, long ldm, int mode, int M, int N, int K, int splits, hipStream_t s) {
+    if (mode == 0) {
+        EpiStore<0, false> e{C, ldc, bias, relu, nullptr, relu_mask, ldm};
+        sbl_launch_gemm<AL, BL, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s);
+    } else if (mode == 1) {
+        EpiStore<1, false> e{C, ldc, bias, relu, nullptr, relu_mask, ldm};
+        sbl_launch_gemm<AL, BL, EpiStore<1, false>, BM, BN>(al, bl, e, M, N, K, 1, s);
+    } else {
+        EpiStore<2, false> e{C, ldc, nullptr, 0, nullptr, nullptr, 0};
+        sbl_launch_gemm<AL, BL, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s);
+    }
+}
+
+template <bool VEC, int BM, int BN>
+static void launch_trans(int transA, int transB, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                         const float* bias, int relu, const float* relu_mask, long ldm, int mode, int M, int N, int K,
+                         int splits, hipStream_t s) {
+    if (!transA && transB) {
+        DenseKC<BM, VEC> al{A, lda, M};
+        DenseKC<BN, VEC> bl{B, ldb, N};
+        launch_mode<DenseKC<BM, VEC>, DenseKC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+    } else if (!transA && !transB) {
+        DenseKC<BM, VEC> al{A, lda, M};
+        DenseMC<BN, VEC> bl{B, ldb, N};
+        launch_mode<DenseKC<BM, VEC>, DenseMC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+    } else if (transA && !transB) {
+        DenseMC<BM, VEC> al{A, lda, M};
+        DenseMC<BN, VEC> bl{B, ldb, N};
+        launch_mode<DenseMC<BM, VEC>, DenseMC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+    } else {
+        DenseMC<BM, VEC> al{A, lda, M};
+        DenseKC<BN, VEC> bl{B, ldb, N};
+        launch_mode<DenseMC<BM, VEC>, DenseKC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+    }
+}
+
+extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
+                            long ldb, float* C, long ldc, const float* bias, int relu, const float* relu_mask, long ldm,
+                            int accumulate, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(M > 0 && N > 0 && K > 0, "sbl_gemm_f32: non-positive dims M=%d N=%d K=%d", M, N, K);
+    SBL_REQUIRE(A && B && C, "sbl_gemm_f32: null operand");
+    SBL_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+                "sbl_gemm_f32: leading dimension too small (lda=%ld ldb=%ld ldc=%ld)", lda, ldb, ldc);
+    SBL_REQUIRE(!relu_mask || ldm >= N, "sbl_gemm_f32: ldm=%ld < N=%d", ldm, N);
+    // float4 path: every row start 16-byte aligned and, for k-contiguous operands, K % 4 == 0
+    bool vec = sbl_aligned16(A) && sbl_aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    if (!transA || transB) vec = vec && (K % 4 == 0);
+    const bool plain = !bias && !relu && !relu_mask;
+    const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
+    const bool big = (M >= 1024 && N >= 256 && tiles64 >= 2048);
+    int splits = 1;
+    if (plain && !big && tiles64 < 256 && K >= 256) {
+        splits = (int)((512 + tiles64 - 1) / tiles64);
+        if (splits > K / 64) splits = K / 64;
+        if (splits < 1) splits = 1;
+    }
+    int mode = accumulate ? 1 : 0;
+    if (splits > 1) {
+        mode = 2;
+        if (!accumulate) SBL_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
+    }
+#define SBL_GO(VEC, BM, BN) \
+    launch_trans<VEC, BM, BN>(transA, transB, A, lda, B, ldb, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s)
+    if (big) {
+        if (vec) SBL_GO(true, 128, 128);
+        else SBL_GO(false, 128, 128);
+    } else {
+        if (vec) SBL_GO(true, 64, 64);
+        else SBL_GO(false, 64, 64);
+    }
+#undef SBL_GO
+    SBL_LAUNCH_CHECK("sbl_gemm_f32");
+    return 0;
+}
+
+// ------------------------------------------------------------------ column sums (bias grads)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ldx, float* __restrict__ out,
+                                                     int M, int N, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + rg; r < r1; r += 4) s += X[(long)r * ldx + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+extern "C" int sbl_colsum_f32(const float* X, long ldx, float* out, int M, int N, int accumulate, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(M > 0 && N > 0 && X && out && ldx >= N, "sbl_colsum_f32: bad args M=%d N=%d ldx=%ld", M, N, ldx);
+    if (!accumulate) SBL_HIP(hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s));
+    int gy = sbl_cdiv(M, 64);
+    if (gy > 64) gy = 64;
+    int rpb = sbl_cdiv(M, gy);
+    hipLaunchKernelGGL(colsum_kernel, dim3(sbl_cdiv(N, 64), gy), dim3(256), 0, s, X, ldx, out, M, N, rpb);
+    SBL_LAUNCH_CHECK("sbl_colsum_f32");
+    return 0;
+}

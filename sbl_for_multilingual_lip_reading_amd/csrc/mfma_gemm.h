@@ -1,0 +1,387 @@
+// fp32 MFMA tile engine shared by the dense GEMMs (Linear fwd/bwd) and the implicit-GEMM
+// convolutions (ResNet trunk fwd / dgrad / wgrad).
+//
+//   C[M,N] = sum_k A(m,k) * B(n,k)        (both operands are presented "k-major" in LDS)
+//
+// * 256-thread workgroup = 4 wavefronts (64 lanes) laid out 2x2; each wave owns a
+//   (BM/2)x(BN/2) sub-tile made of 32x32 v_mfma_f32_32x32x2_f32 accumulators — exact fp32
+//   (bitwise an fmaf chain), 157 TF peak on gfx950, which is what the 1e-3 parity bar needs.
+// * LDS image As[BK][BM+4] / Bs[BK][BN+4] (k-major): the MFMA operand read
+//   As[2*ks + (lane>>5)][m + (lane&31)] is 32 consecutive dwords per half-wave => conflict-free
+//   ds_read_b32; two LDS buffers, one barrier per K-step, next tile's global loads issued
+//   before the MFMA block and written to the other buffer after it (register staging: the
+//   conv gathers are per-lane scattered, so LDS-DMA's lane-linear image does not apply).
+// * Loaders are functors: dense k-contiguous rows (transposed on the LDS write), dense
+//   m-contiguous rows (16-byte LDS writes), and NHWC im2col gathers of both kinds.
+// * Epilogues are functors: store (+bias, +ReLU, +=), float-atomic accumulate (split-K),
+//   and store + per-channel sum / sum-of-squares (training BatchNorm statistics fused into
+//   the producing convolution, double atomics).
+#pragma once
+#include "sbl_common.h"
+
+#define SBL_BK 16
+
+// ------------------------------------------------------------------ loaders
+// Dense, k-contiguous: element (r,k) at p[r*ld + k].  Used for X[M,K] and W[N,K] of Linear.
+template <int BR, bool VEC>
+struct DenseKC {
+    const float* p;
+    long ld;
+    int rows;
+    struct State {
+        const float* rp[BR / 64];
+        bool ok[BR / 64];
+        int kq;
+    };
+    struct Regs {
+        float4 v[BR / 64];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.kq = (tid & 3) * 4;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            int r = r0 + ps * 64 + (tid >> 2);
+            s.ok[ps] = r < rows;
+            s.rp[ps] = p + (long)(s.ok[ps] ? r : 0) * ld;
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+        const int k = k0 + s.kq;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s.ok[ps]) {
+                if (VEC) {
+                    if (k < kend) v = *reinterpret_cast<const float4*>(s.rp[ps] + k);
+                } else {
+                    if (k + 0 < kend) v.x = s.rp[ps][k + 0];
+                    if (k + 1 < kend) v.y = s.rp[ps][k + 1];
+                    if (k + 2 < kend) v.z = s.rp[ps][k + 2];
+                    if (k + 3 < kend) v.w = s.rp[ps][k + 3];
+                }
+            }
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            const int row = ps * 64 + (tid >> 2);
+            lds[s.kq + 0][row] = r.v[ps].x;
+            lds[s.kq + 1][row] = r.v[ps].y;
+            lds[s.kq + 2][row] = r.v[ps].z;
+            lds[s.kq + 3][row] = r.v[ps].w;
+        }
+    }
+};
+
+// Dense, m-contiguous: element (r,k) at p[k*ld + r].  Used for dY^T / X in weight-gradient
+// GEMMs and for W[K,N] in input-gradient GEMMs.
+template <int BR, bool VEC>
+struct DenseMC {
+    const float* p;
+    long ld;
+    int rows;
+    static constexpr int TPR = BR / 4;           // threads per k-row
+    static constexpr int RPP = 256 / TPR;        // k-rows per pass
+    static constexpr int NP = SBL_BK / RPP;      // passes
+    struct State {
+        int c, kr;
+    };
+    struct Regs {
+        float4 v[NP];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.c = r0 + (tid % TPR) * 4;
+        s.kr = tid / TPR;
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int k = k0 + s.kr + ps * RPP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend) {
+                const float* q = p + (long)k * ld + s.c;
+                if (VEC && s.c + 3 < rows) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (s.c + 0 < rows) v.x = q[0];
+                    if (s.c + 1 < rows) v.y = q[1];
+                    if (s.c + 2 < rows) v.z = q[2];
+                    if (s.c + 3 < rows) v.w = q[3];
+                }
+            }
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
+    }
+};
+
+// NHWC convolution geometry (one struct for fwd / dgrad / wgrad gathers).
+//   "out" grid (OH,OW) indexes GEMM rows; "src" tensor (SH,SW,C) is what gets gathered.
+//   fwd / wgrad:  src = x (H,W,Cin),  out = y grid (Ho,Wo):   ih = oh*stride - pad + kh
+//   dgrad:        src = dy (Ho,Wo,Cout), out = x grid (H,W):  t = oh + pad - kh, valid iff t%stride==0,
+//                                                              ih = t/stride < SH
+struct ConvGeom {
+    int NIMG, OH, OW;   // GEMM-row grid
+    int SH, SW, C;      // gathered tensor (NHWC)
+    int KH, KW, stride, pad;
+};
+
+template <bool DGRAD>
+__device__ __forceinline__ bool conv_src_coord(const ConvGeom& g, int oh, int ow, int kh, int kw, int& ih, int& iw) {
+    if (!DGRAD) {
+        ih = oh * g.stride - g.pad + kh;
+        iw = ow * g.stride - g.pad + kw;
+        return (unsigned)ih < (unsigned)g.SH && (unsigned)iw < (unsigned)g.SW;
+    } else {
+        int th = oh + g.pad - kh, tw = ow + g.pad - kw;
+        if (th < 0 || tw < 0) return false;
+        if (g.stride == 2) {
+            if ((th | tw) & 1) return false;
+            ih = th >> 1;
+            iw = tw >> 1;
+        } else {
+            ih = th;
+            iw = tw;
+        }
+        return ih < g.SH && iw < g.SW;
+    }
+}
+
+// im2col rows, k-contiguous: row = output pixel, k = (kh,kw,c) with c fastest.  C % 16 == 0
+// so one BK slice never straddles a tap and each lane's float4 stays inside one pixel.
+template <int BR, bool DGRAD>
+struct ConvGatherKC {
+    const float* p;
+    ConvGeom g;
+    int rows;   // NIMG*OH*OW
+    struct State {
+        int img[BR / 64], oh[BR / 64], ow[BR / 64];
+        bool ok[BR / 64];
+        int kq;
+    };
+    struct Regs {
+        float4 v[BR / 64];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.kq = (tid & 3) * 4;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            int r = r0 + ps * 64 + (tid >> 2);
+            s.ok[ps] = r < rows;
+            if (!s.ok[ps]) r = 0;
+            int hw = g.OH * g.OW;
+            s.img[ps] = r / hw;
+            int rem = r - s.img[ps] * hw;
+            s.oh[ps] = rem / g.OW;
+            s.ow[ps] = rem - s.oh[ps] * g.OW;
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+        const int tap = k0 / g.C;          // block-uniform
+        const int c = k0 - tap * g.C + s.kq;
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int ih, iw;
+            if (s.ok[ps] && k0 < kend && conv_src_coord<DGRAD>(g, s.oh[ps], s.ow[ps], kh, kw, ih, iw))
+                v = *reinterpret_cast<const float4*>(p + (((long)s.img[ps] * g.SH + ih) * g.SW + iw) * g.C + c);
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            const int row = ps * 64 + (tid >> 2);
+            lds[s.kq + 0][row] = r.v[ps].x;
+            lds[s.kq + 1][row] = r.v[ps].y;
+            lds[s.kq + 2][row] = r.v[ps].z;
+            lds[s.kq + 3][row] = r.v[ps].w;
+        }
+    }
+};
+
+// im2col columns, m-contiguous (weight gradient B operand): GEMM-k = output pixel,
+// GEMM-row r = (kh,kw,c) with c fastest; a lane's 4 consecutive r share one tap (C % 4 == 0).
+template <int BR>
+struct ConvGatherMC {
+    const float* p;
+    ConvGeom g;
+    int rows;   // KH*KW*C
+    static constexpr int TPR = BR / 4;
+    static constexpr int RPP = 256 / TPR;
+    static constexpr int NP = SBL_BK / RPP;
+    struct State {
+        int c, kh, kw, kr;
+        bool ok;
+    };
+    struct Regs {
+        float4 v[NP];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        int r = r0 + (tid % TPR) * 4;
+        s.ok = r < rows;
+        if (!s.ok) r = 0;
+        int tap = r / g.C;
+        s.c = r - tap * g.C;
+        s.kh = tap / g.KW;
+        s.kw = tap - s.kh * g.KW;
+        s.kr = tid / TPR;
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+        const int hw = g.OH * g.OW;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int k = k0 + s.kr + ps * RPP;   // output pixel index
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s.ok && k < kend) {
+                int img = k / hw;
+                int rem = k - img * hw;
+                int oh = rem / g.OW, ow = rem - oh * g.OW;
+                int ih, iw;
+                if (conv_src_coord<false>(g, oh, ow, s.kh, s.kw, ih, iw))
+                    v = *reinterpret_cast<const float4*>(p + (((long)img * g.SH + ih) * g.SW + iw) * g.C + s.c);
+            }
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
+    }
+};
+
+// ------------------------------------------------------------------ epilogues
+// MODE 0: C = acc (+bias) (ReLU)   MODE 1: C += acc (non-atomic; one block per tile)
+// MODE 2: atomicAdd(C, acc) (split-K; C pre-zeroed or accumulating)
+template <int MODE, bool STATS>
+struct EpiStore {
+    static constexpr bool kStats = STATS;
+    float* C;
+    long ldc;
+    const float* bias;   // [N] or nullptr
+    int relu;
+    double* stats;       // [2*N] (sum, sumsq) when STATS
+    const float* relu_mask;   // multiply by (mask[m*ldm+n] > 0) (ReLU backward) or nullptr
+    long ldm;
+    __device__ __forceinline__ void tile(const f32x16& a, int mbase, int n, int M, int N, int lane,
+                                         float& s1, float& s2) const {
+        if (n >= N) return;
+        const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) {
+                float v = a[r] + b;
+                if (relu) v = fmaxf(v, 0.f);
+                if (relu_mask) v = relu_mask[(long)m * ldm + n] > 0.f ? v : 0.f;
+                float* q = C + (long)m * ldc + n;
+                if (MODE == 0) *q = v;
+                else if (MODE == 1) *q += v;
+                else atomicAdd(q, v);
+                if (STATS) {
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------ kernel
+template <class AL, class BL, class EPI, int BM, int BN>
+__global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, int M, int N, int K, int kchunk) {
+    __shared__ __attribute__((aligned(16))) float As[2][SBL_BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SBL_BK][BN + 4];
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+
+    typename AL::State sa;
+    typename BL::State sb;
+    typename AL::Regs ra;
+    typename BL::Regs rb;
+    al.init(sa, m0, tid);
+    bl.init(sb, n0, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    al.load(sa, kbeg, kend, ra);
+    bl.load(sb, kbeg, kend, rb);
+    al.store(As[0], sa, ra, tid);
+    bl.store(Bs[0], sb, rb, tid);
+    __syncthreads();
+
+    const int arow = wm * (BM / 2) + (lane & 31);
+    const int brow = wn * (BN / 2) + (lane & 31);
+    const int kh = lane >> 5;
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += SBL_BK) {
+        const bool has_next = (k0 + SBL_BK) < kend;
+        if (has_next) {
+            al.load(sa, k0 + SBL_BK, kend, ra);
+            bl.load(sb, k0 + SBL_BK, kend, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < SBL_BK / 2; ++ks) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][2 * ks + kh][arow + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][2 * ks + kh][brow + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) {
+            al.store(As[cur ^ 1], sa, ra, tid);
+            bl.store(Bs[cur ^ 1], sb, rb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / 2) + i * 32, n, M, N, lane, s1, s2);
+        if (EPI::kStats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32 && n < N) {
+                atomicAdd(epi.stats + n, (double)s1);
+                atomicAdd(epi.stats + N + n, (double)s2);
+            }
+        }
+    }
+}
+
+template <class AL, class BL, class EPI, int BM, int BN>
+static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int splits,
+                                   hipStream_t s) {
+    int kchunk = sbl_cdiv(sbl_cdiv(K, splits), SBL_BK) * SBL_BK;
+    int nz = sbl_cdiv(K, kchunk);
+    dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN>), grid, dim3(256), 0, s, al, bl, epi, M, N, K, kchunk);
+}

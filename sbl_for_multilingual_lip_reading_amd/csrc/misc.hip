@@ -1,0 +1,276 @@
+// Small decoder-side kernels: embedding + positional encoding, SBL cross-direction fusion, greedy /
+// teacher-forced token feedback (kept on the device: no host sync inside the 16-step loop), label-smoothed
+// cross entropy, fused Adam.
+#include "sbl_common.h"
+
+static inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+// ------------------------------------------------------------------ embedding + PE: decoder.py:116-120
+__global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __restrict__ tok, long ldt,
+                                                           const float* __restrict__ emb, const float* __restrict__ pe,
+                                                           float* __restrict__ out, int B, int L, int D4, int V) {
+    const long n4 = (long)B * L * D4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const long bl = i / D4;
+        const int l = (int)(bl % L);
+        const int b = (int)(bl / L);
+        long t = tok[(long)b * ldt + l];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);   // ids are produced on-device from argmax/gold: always in range
+        const float4 e = reinterpret_cast<const float4*>(emb)[t * D4 + c];
+        const float4 p = reinterpret_cast<const float4*>(pe)[(long)l * D4 + c];
+        reinterpret_cast<float4*>(out)[i] = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, long ldt, const float* __restrict__ dy,
+                                                        float* __restrict__ demb, int B, int L, int D, int V) {
+    const long n = (long)B * L * D;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D);
+        const long bl = i / D;
+        const int l = (int)(bl % L);
+        const int b = (int)(bl / L);
+        long t = tok[(long)b * ldt + l];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+        atomicAdd(demb + t * D + c, dy[i]);
+    }
+}
+extern "C" int sbl_embed_pe_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B, int L,
+                                int D, int V, sbl_stream_t stream) {
+    SBL_REQUIRE(tok && emb && pe && out && B > 0 && L > 0 && D > 0 && D % 4 == 0 && V > 0 && ldt >= L, "sbl_embed_pe_fwd: bad args");
+    SBL_REQUIRE(sbl_aligned16(emb) && sbl_aligned16(pe) && sbl_aligned16(out), "sbl_embed_pe_fwd: unaligned");
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(ew_grid((long)B * L * D / 4)), dim3(256), 0, (hipStream_t)stream, tok, ldt,
+                       emb, pe, out, B, L, D / 4, V);
+    SBL_LAUNCH_CHECK("sbl_embed_pe_fwd");
+    return 0;
+}
+extern "C" int sbl_embed_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, int L, int D, int V,
+                             sbl_stream_t stream) {
+    SBL_REQUIRE(tok && dy && demb && B > 0 && L > 0 && D > 0 && V > 0 && ldt >= L, "sbl_embed_bwd: bad args");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((long)B * L * D)), dim3(256), 0, (hipStream_t)stream, tok, ldt, dy,
+                       demb, B, L, D, V);
+    SBL_LAUNCH_CHECK("sbl_embed_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ SBL fusion: decoder.py:132-143,160-164
+// fwd: A' = A + flip(B), B' = 2B + flip(A).  bwd (adjoint): dA = dA' + flip(dB'), dB = flip(dA') + 2 dB'.
+template <bool BWD>
+__global__ __launch_bounds__(256) void fusion_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ a2, float* __restrict__ b2, int B, int L, int D4) {
+    const long n4 = (long)B * L * D4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const long bl = i / D4;
+        const int l = (int)(bl % L);
+        const long bb = bl / L;
+        const long f = (bb * L + (L - 1 - l)) * D4 + c;   // time-flipped position
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        const float4 xf = reinterpret_cast<const float4*>(a)[f], yf = reinterpret_cast<const float4*>(b)[f];
+        float4 o1, o2;
+        if (!BWD) {
+            o1 = make_float4(x.x + yf.x, x.y + yf.y, x.z + yf.z, x.w + yf.w);
+            o2 = make_float4(2.f * y.x + xf.x, 2.f * y.y + xf.y, 2.f * y.z + xf.z, 2.f * y.w + xf.w);
+        } else {   // a = dA', b = dB'
+            o1 = make_float4(x.x + yf.x, x.y + yf.y, x.z + yf.z, x.w + yf.w);
+            o2 = make_float4(xf.x + 2.f * y.x, xf.y + 2.f * y.y, xf.z + 2.f * y.z, xf.w + 2.f * y.w);
+        }
+        reinterpret_cast<float4*>(a2)[i] = o1;
+        reinterpret_cast<float4*>(b2)[i] = o2;
+    }
+}
+static int fusion_common(const char* who, const float* a, const float* b, float* a2, float* b2, int B, int L, int D,
+                         bool bwd, sbl_stream_t stream) {
+    SBL_REQUIRE(a && b && a2 && b2 && B > 0 && L > 0 && D > 0 && D % 4 == 0, "%s: bad args", who);
+    SBL_REQUIRE(a2 != a && a2 != b && b2 != a && b2 != b && a2 != b2, "%s: outputs must not alias inputs (time flip)", who);
+    SBL_REQUIRE(sbl_aligned16(a) && sbl_aligned16(b) && sbl_aligned16(a2) && sbl_aligned16(b2), "%s: unaligned", who);
+    const long n4 = (long)B * L * D / 4;
+    if (bwd) hipLaunchKernelGGL(fusion_kernel<true>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, a2, b2, B, L, D / 4);
+    else hipLaunchKernelGGL(fusion_kernel<false>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, a2, b2, B, L, D / 4);
+    SBL_LAUNCH_CHECK(who);
+    return 0;
+}
+extern "C" int sbl_fusion_fwd(const float* a, const float* b, float* a2, float* b2, int B, int L, int D, sbl_stream_t stream) {
+    return fusion_common("sbl_fusion_fwd", a, b, a2, b2, B, L, D, false, stream);
+}
+extern "C" int sbl_fusion_bwd(const float* da2, const float* db2, float* da, float* db, int B, int L, int D, sbl_stream_t stream) {
+    return fusion_common("sbl_fusion_bwd", da2, db2, da, db, B, L, D, true, stream);
+}
+
+// ------------------------------------------------------------------ token feedback: decoder.py:173-186
+// one wavefront per batch row; argmax returns the FIRST maximal index (torch.argmax tie-break on CPU)
+__global__ __launch_bounds__(256) void argmax_select_kernel(const float* __restrict__ pred, long ldp,
+                                                            const int64_t* __restrict__ gold, long ldg,
+                                                            int64_t* __restrict__ ys, long ldy, int step, int use_argmax,
+                                                            const int32_t* __restrict__ coins, int B, int V) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int own = coins ? coins[step] : use_argmax;
+    if (!own) {
+        if (lane == 0) ys[(long)b * ldy + step + 1] = gold[(long)b * ldg + step];
+        return;
+    }
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+        const float v = pred[(long)b * ldp + c];
+        if (v > best) {
+            best = v;
+            bi = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) ys[(long)b * ldy + step + 1] = bi == 0x7fffffff ? 0 : bi;
+}
+extern "C" int sbl_argmax_select(const float* pred, long ldp, const int64_t* gold, long ldg, int64_t* ys, long ldy, int step,
+                                 int use_argmax, const int32_t* coins_dev, int B, int V, sbl_stream_t stream) {
+    SBL_REQUIRE(pred && ys && B > 0 && V > 0 && ldp >= V && step >= 0 && step + 1 < ldy, "sbl_argmax_select: bad args");
+    SBL_REQUIRE(gold || (use_argmax && !coins_dev), "sbl_argmax_select: gold required unless always-argmax");
+    SBL_REQUIRE(!gold || step < ldg, "sbl_argmax_select: step beyond gold width");
+    hipLaunchKernelGGL(argmax_select_kernel, dim3(sbl_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, pred, ldp, gold, ldg,
+                       ys, ldy, step, use_argmax, coins_dev, B, V);
+    SBL_LAUNCH_CHECK("sbl_argmax_select");
+    return 0;
+}
+
+// ------------------------------------------------------------------ label-smoothed CE: loss.py:27-52
+// one wavefront per row (C <= 64*4).  q = onehot*(1-eps) + (1-onehot)*eps/C (rows do not sum to 1: kept).
+// eps == 0 reduces to plain cross entropy with ignore_index (loss.py:48-50).
+__global__ __launch_bounds__(256) void smoothed_ce_fwd_kernel(const float* __restrict__ pred, const int64_t* __restrict__ gold,
+                                                              float* __restrict__ out3, int R, int C, float eps, int ignore_id) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const long g = gold[r];
+    if (g == ignore_id) return;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = pred[(long)r * C + c];
+        if (v > mx) {
+            mx = v;
+            am = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oi < am)) {
+            mx = ov;
+            am = oi;
+        }
+    }
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += __expf(pred[(long)r * C + c] - mx);
+    const float lse = __logf(wave_sum(se)) + mx;
+    float loss = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float qv = (c == g) ? (1.f - eps) : eps / (float)C;
+        loss -= qv * (pred[(long)r * C + c] - lse);
+    }
+    loss = wave_sum(loss);
+    if (lane == 0) {
+        atomicAdd(out3 + 0, loss);
+        atomicAdd(out3 + 1, 1.f);
+        if (am == g) atomicAdd(out3 + 2, 1.f);
+    }
+}
+// d loss_mean / d pred[r][c] = gscale/n_valid * (sum(q) * softmax - q) on valid rows, 0 elsewhere
+__global__ __launch_bounds__(256) void smoothed_ce_bwd_kernel(const float* __restrict__ pred, const int64_t* __restrict__ gold,
+                                                              const float* __restrict__ out3, const float* __restrict__ gscale,
+                                                              float* __restrict__ dpred, int R, int C, float eps, int ignore_id) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const long g = gold[r];
+    if (g == ignore_id) {
+        for (int c = lane; c < C; c += 64) dpred[(long)r * C + c] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, pred[(long)r * C + c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += __expf(pred[(long)r * C + c] - mx);
+    se = wave_sum(se);
+    const float scale = gscale[0] / out3[1];
+    const float qsum = (1.f - eps) + (float)(C - 1) * eps / (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float sm = __expf(pred[(long)r * C + c] - mx) / se;
+        const float qv = (c == g) ? (1.f - eps) : eps / (float)C;
+        dpred[(long)r * C + c] = scale * (qsum * sm - qv);
+    }
+}
+extern "C" int sbl_smoothed_ce_fwd(const float* pred, const int64_t* gold, float* out3, int R, int C, float eps, int ignore_id,
+                                   sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(pred && gold && out3 && R > 0 && C > 0 && eps >= 0.f && eps < 1.f, "sbl_smoothed_ce_fwd: bad args");
+    SBL_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(float), s));
+    hipLaunchKernelGGL(smoothed_ce_fwd_kernel, dim3(sbl_cdiv(R, 4)), dim3(256), 0, s, pred, gold, out3, R, C, eps, ignore_id);
+    SBL_LAUNCH_CHECK("sbl_smoothed_ce_fwd");
+    return 0;
+}
+extern "C" int sbl_smoothed_ce_bwd(const float* pred, const int64_t* gold, const float* out3, const float* gscale,
+                                   float* dpred, int R, int C, float eps, int ignore_id, sbl_stream_t stream) {
+    SBL_REQUIRE(pred && gold && out3 && gscale && dpred && R > 0 && C > 0, "sbl_smoothed_ce_bwd: bad args");
+    hipLaunchKernelGGL(smoothed_ce_bwd_kernel, dim3(sbl_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, pred, gold, out3,
+                       gscale, dpred, R, C, eps, ignore_id);
+    SBL_LAUNCH_CHECK("sbl_smoothed_ce_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused Adam over a flat buffer
+// torch.optim.Adam semantics (SBL/train.py:75): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float b1, float b2, float eps,
+                                                   float step_size, float inv_sqrt_bc2, float gscale) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+extern "C" int sbl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, int step, float grad_scale, sbl_stream_t stream) {
+    SBL_REQUIRE(p && g && m && v && n > 0 && step >= 1, "sbl_adam_step: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    SBL_LAUNCH_CHECK("sbl_adam_step");
+    return 0;
+}
+
+// ------------------------------------------------------------------ y[m,:] = x[m,:] * s[m]
+// the `*= non_pad_mask` of encoder.py:86,89 / decoder.py:399,403,406 for ragged input_lengths
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                       float* __restrict__ y, long n4, int D4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float f = s[i / D4];
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<float4*>(y)[i] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+    }
+}
+extern "C" int sbl_rowscale(const float* x, const float* s, float* y, long M, int D, sbl_stream_t stream) {
+    SBL_REQUIRE(x && s && y && M > 0 && D > 0 && D % 4 == 0 && sbl_aligned16(x) && sbl_aligned16(y), "sbl_rowscale: bad args");
+    const long n4 = M * (D / 4);
+    hipLaunchKernelGGL(rowscale_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, s, y, n4, D / 4);
+    SBL_LAUNCH_CHECK("sbl_rowscale");
+    return 0;
+}

@@ -1,0 +1,348 @@
+// HBM-bound normalisation kernels: trunk BatchNorm apply / backward (NHWC, float4 over channels),
+// residual + LayerNorm forward / backward (one wavefront per 512-wide row, shuffle reductions),
+// dropout, positional-encoding add.
+#include "sbl_common.h"
+
+// ------------------------------------------------------------------ BatchNorm apply (train or eval stats)
+// y = [relu](gamma*(x-mean)*invstd + beta [+ res]);  video_frontend.py:30-39 (BasicBlock.forward)
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ y, long n4, int C4, int relu) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = (v.x - mu.x) * is.x * ga.x + be.x;
+        o.y = (v.y - mu.y) * is.y * ga.y + be.y;
+        o.z = (v.z - mu.z) * is.z * ga.z + be.z;
+        o.w = (v.w - mu.w) * is.w * ga.w + be.w;
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// backward pass 1: per-channel sum g and sum g*xhat, g = dy * (y > 0 if relu).
+// A thread keeps one channel quad for its whole grid-stride walk (stride is a multiple of C4).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* __restrict__ sums,
+                                                            long rows, int C, int relu, int rows_per_block) {
+    // blockDim = 256 = rg row-groups x C4 channel quads (C4 = C/4 divides 256)
+    __shared__ float red[256][8];
+    const int C4 = C / 4;
+    const int rg = 256 / C4;                      // row groups per block
+    const int q0 = threadIdx.x % C4, g0 = threadIdx.x / C4;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    {
+        const int c = q0 * 4;
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        float sg[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+        for (long r = r0 + g0; r < r1; r += rg) {
+            const long o = r * C + c;
+            float4 g = *reinterpret_cast<const float4*>(dy + o);
+            if (relu) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + o);
+                if (!(yy.x > 0.f)) g.x = 0.f;
+                if (!(yy.y > 0.f)) g.y = 0.f;
+                if (!(yy.z > 0.f)) g.z = 0.f;
+                if (!(yy.w > 0.f)) g.w = 0.f;
+            }
+            const float4 v = *reinterpret_cast<const float4*>(x + o);
+            sg[0] += g.x; sg[1] += g.y; sg[2] += g.z; sg[3] += g.w;
+            sx[0] += g.x * (v.x - mu.x) * is.x;
+            sx[1] += g.y * (v.y - mu.y) * is.y;
+            sx[2] += g.z * (v.z - mu.z) * is.z;
+            sx[3] += g.w * (v.w - mu.w) * is.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[threadIdx.x][k] = sg[k];
+            red[threadIdx.x][4 + k] = sx[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < rg; ++g)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += red[g * C4 + threadIdx.x][k];
+        const int c = threadIdx.x * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(sums + c + k, (double)t[k]);
+            atomicAdd(sums + C + c + k, (double)t[4 + k]);
+        }
+    }
+}
+
+// backward pass 2: dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g; dgamma/dbeta from sums
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, float* __restrict__ dx,
+                                                           float* __restrict__ dres, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, long n4, long rows, int C, int relu) {
+    const int C4 = C / 4;
+    const double inv = 1.0 / (double)rows;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            dbeta[c] = (float)sums[c];
+            dgamma[c] = (float)sums[C + c];
+        }
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            const float4 yy = reinterpret_cast<const float4*>(y)[i];
+            if (!(yy.x > 0.f)) g.x = 0.f;
+            if (!(yy.y > 0.f)) g.y = 0.f;
+            if (!(yy.z > 0.f)) g.z = 0.f;
+            if (!(yy.w > 0.f)) g.w = 0.f;
+        }
+        if (dres) reinterpret_cast<float4*>(dres)[i] = g;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float mg0 = (float)(sums[c] * inv), mg1 = (float)(sums[c + 1] * inv), mg2 = (float)(sums[c + 2] * inv),
+                    mg3 = (float)(sums[c + 3] * inv);
+        const float mx0 = (float)(sums[C + c] * inv), mx1 = (float)(sums[C + c + 1] * inv),
+                    mx2 = (float)(sums[C + c + 2] * inv), mx3 = (float)(sums[C + c + 3] * inv);
+        float4 o;
+        o.x = ga.x * is.x * (g.x - mg0 - (v.x - mu.x) * is.x * mx0);
+        o.y = ga.y * is.y * (g.y - mg1 - (v.y - mu.y) * is.y * mx1);
+        o.z = ga.z * is.z * (g.z - mg2 - (v.z - mu.z) * is.z * mx2);
+        o.w = ga.w * is.w * (g.w - mg3 - (v.w - mu.w) * is.w * mx3);
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+static inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+extern "C" int sbl_bn_apply_fwd(const float* x, const float* res, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float* y, long rows, int C, int relu,
+                                sbl_stream_t stream) {
+    SBL_REQUIRE(x && mean && invstd && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0, "sbl_bn_apply_fwd: bad args rows=%ld C=%d", rows, C);
+    SBL_REQUIRE(sbl_aligned16(x) && sbl_aligned16(y) && (!res || sbl_aligned16(res)), "sbl_bn_apply_fwd: unaligned");
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, res, mean, invstd,
+                       gamma, beta, y, n4, C / 4, relu);
+    SBL_LAUNCH_CHECK("sbl_bn_apply_fwd");
+    return 0;
+}
+
+extern "C" int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                 double* sums, long rows, int C, int relu, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(dy && x && mean && invstd && sums && rows > 0 && C >= 4 && C % 4 == 0 && (!relu || y), "sbl_bn_bwd_reduce: bad args");
+    SBL_REQUIRE((C / 4) <= 256 && 256 % (C / 4) == 0, "sbl_bn_bwd_reduce: C=%d unsupported (C/4 must divide 256)", C);
+    SBL_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
+    long blocks = (rows + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    const int rpb = (int)((rows + blocks - 1) / blocks);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0, s, dy, y, x, mean, invstd,
+                       sums, rows, C, relu, rpb);
+    SBL_LAUNCH_CHECK("sbl_bn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                const float* gamma, const double* sums, float* dx, float* dres, float* dgamma,
+                                float* dbeta, long rows, int C, int relu, sbl_stream_t stream) {
+    SBL_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && dgamma && dbeta && rows > 0 && C >= 4 && C % 4 == 0 && (!relu || y),
+                "sbl_bn_bwd_apply: bad args");
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, invstd,
+                       gamma, sums, dx, dres, dgamma, dbeta, n4, rows, C, relu);
+    SBL_LAUNCH_CHECK("sbl_bn_bwd_apply");
+    return 0;
+}
+
+// ------------------------------------------------------------------ dropout
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                      uint32_t thresh, float scale, const uint64_t* __restrict__ seed,
+                                                      uint64_t offset) {
+    const uint64_t sd = *seed;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = sbl_keep(sd, offset, (uint64_t)i, thresh) ? x[i] * scale : 0.f;
+}
+__global__ void seed_bump_kernel(uint64_t* seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
+
+extern "C" int sbl_dropout(const float* x, float* y, long n, float p, const uint64_t* seed, uint64_t offset,
+                           sbl_stream_t stream) {
+    SBL_REQUIRE(x && y && seed && n > 0 && p >= 0.f && p < 1.f, "sbl_dropout: bad args n=%ld p=%f", n, p);
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, sbl_drop_thresh(p),
+                       1.f / (1.f - p), seed, offset);
+    SBL_LAUNCH_CHECK("sbl_dropout");
+    return 0;
+}
+extern "C" int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream) {
+    SBL_REQUIRE(seed, "sbl_seed_bump: null");
+    hipLaunchKernelGGL(seed_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+    SBL_LAUNCH_CHECK("sbl_seed_bump");
+    return 0;
+}
+
+// ------------------------------------------------------------------ residual + LayerNorm (D = 512)
+// One wavefront per row: 8 floats per lane (two float4), mean / variance by wave shuffles.
+// attention.py:57-58, module.py:50-51, encoder.py:53-54 (torch LayerNorm: biased variance, eps inside sqrt)
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ y, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int M, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const long o = (long)row * 512;
+    float v[8];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + o + lane * 4);
+    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(x + o + 256 + lane * 4);
+    if (res) {
+        const float4 r0 = *reinterpret_cast<const float4*>(res + o + lane * 4);
+        const float4 r1 = *reinterpret_cast<const float4*>(res + o + 256 + lane * 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+    const float mu = wave_sum(s) * (1.f / 512.f);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q += (v[k] - mu) * (v[k] - mu);
+    const float rs = rsqrtf(wave_sum(q) * (1.f / 512.f) + eps);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 4), g1 = *reinterpret_cast<const float4*>(gamma + 256 + lane * 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + lane * 4), b1 = *reinterpret_cast<const float4*>(beta + 256 + lane * 4);
+    float4 o0, o1;
+    o0.x = (v[0] - mu) * rs * g0.x + b0.x; o0.y = (v[1] - mu) * rs * g0.y + b0.y;
+    o0.z = (v[2] - mu) * rs * g0.z + b0.z; o0.w = (v[3] - mu) * rs * g0.w + b0.w;
+    o1.x = (v[4] - mu) * rs * g1.x + b1.x; o1.y = (v[5] - mu) * rs * g1.y + b1.y;
+    o1.z = (v[6] - mu) * rs * g1.z + b1.z; o1.w = (v[7] - mu) * rs * g1.w + b1.w;
+    *reinterpret_cast<float4*>(y + o + lane * 4) = o0;
+    *reinterpret_cast<float4*>(y + o + 256 + lane * 4) = o1;
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+// dz = rstd*(gamma*dy - mean(gamma*dy) - xhat*mean(gamma*dy*xhat)); dgamma += dy*xhat, dbeta += dy (column sums:
+// each wave walks its rows keeping 8 per-lane partials, LDS-combined per block, then float atomics)
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ res, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                float* __restrict__ dz, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int M, int rows_per_block) {
+    __shared__ float red[4][2][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 4), g1 = *reinterpret_cast<const float4*>(gamma + 256 + lane * 4);
+    const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const long o = (long)row * 512;
+        float v[8], d[8];
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + o + lane * 4);
+        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(x + o + 256 + lane * 4);
+        if (res) {
+            const float4 q0 = *reinterpret_cast<const float4*>(res + o + lane * 4);
+            const float4 q1 = *reinterpret_cast<const float4*>(res + o + 256 + lane * 4);
+            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
+            v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+        }
+        *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dy + o + lane * 4);
+        *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(dy + o + 256 + lane * 4);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f, xh[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            xh[k] = (v[k] - mu) * rs;
+            const float gd = ga[k] * d[k];
+            s1 += gd;
+            s2 += gd * xh[k];
+            dg[k] += d[k] * xh[k];
+            db[k] += d[k];
+        }
+        s1 = wave_sum(s1) * (1.f / 512.f);
+        s2 = wave_sum(s2) * (1.f / 512.f);
+        float out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = rs * (ga[k] * d[k] - s1 - xh[k] * s2);
+        *reinterpret_cast<float4*>(dz + o + lane * 4) = *reinterpret_cast<float4*>(out);
+        *reinterpret_cast<float4*>(dz + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = (k < 4 ? 0 : 256) + lane * 4 + (k & 3);
+        red[wave][0][c] = dg[k];
+        red[wave][1][c] = db[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
+        atomicAdd(dbeta + c, red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
+    }
+}
+
+extern "C" int sbl_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                     float* mean, float* rstd, int M, int D, float eps, sbl_stream_t stream) {
+    SBL_REQUIRE(D == 512, "sbl_add_layernorm_fwd: D=%d (only d_model=512 is built: optimizer.py:8, decoder.py:59)", D);
+    SBL_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0, "sbl_add_layernorm_fwd: bad args");
+    SBL_REQUIRE(sbl_aligned16(x) && sbl_aligned16(y) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma) && sbl_aligned16(beta), "sbl_add_layernorm_fwd: unaligned");
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(sbl_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
+                       beta, y, mean, rstd, M, eps);
+    SBL_LAUNCH_CHECK("sbl_add_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int sbl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
+                                     const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta, int M,
+                                     int D, sbl_stream_t stream) {
+    SBL_REQUIRE(D == 512, "sbl_add_layernorm_bwd: D=%d", D);
+    SBL_REQUIRE(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && M > 0, "sbl_add_layernorm_bwd: bad args");
+    SBL_REQUIRE(sbl_aligned16(dy) && sbl_aligned16(x) && sbl_aligned16(dz) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma), "sbl_add_layernorm_bwd: unaligned");
+    int blocks = sbl_cdiv(M, 16);
+    if (blocks > 256) blocks = 256;
+    const int rpb = sbl_cdiv(M, blocks);
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(sbl_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, x, res,
+                       gamma, mean, rstd, dz, dgamma, dbeta, M, rpb);
+    SBL_LAUNCH_CHECK("sbl_add_layernorm_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ y = x + pe[row % L]
+__global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                     float* __restrict__ y, long n4, int L, int D4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const int l = (int)((i / D4) % L);
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 p = reinterpret_cast<const float4*>(pe)[(long)l * D4 + c];
+        reinterpret_cast<float4*>(y)[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+extern "C" int sbl_add_pe(const float* x, const float* pe, float* y, int B, int L, int D, sbl_stream_t stream) {
+    SBL_REQUIRE(x && pe && y && B > 0 && L > 0 && D > 0 && D % 4 == 0, "sbl_add_pe: bad args");
+    SBL_REQUIRE(sbl_aligned16(x) && sbl_aligned16(pe) && sbl_aligned16(y), "sbl_add_pe: unaligned");
+    const long n4 = (long)B * L * (D / 4);
+    hipLaunchKernelGGL(add_pe_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, pe, y, n4, L, D / 4);
+    SBL_LAUNCH_CHECK("sbl_add_pe");
+    return 0;
+}

@@ -1,0 +1,74 @@
+// Shared device/host helpers for libsbl_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sbl_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SBL_WAVE 64
+
+// ---- error plumbing: 0 on success, hipError_t / negative code otherwise; text in sbl_last_error()
+void sbl_set_error(const char* fmt, ...);
+#define SBL_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            sbl_set_error(__VA_ARGS__);                         \
+            return SBL_ERR_INVALID;                             \
+        }                                                       \
+    } while (0)
+#define SBL_LAUNCH_CHECK(name)                                                    \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            sbl_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                      \
+        }                                                                         \
+    } while (0)
+#define SBL_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            sbl_set_error("%s failed: %s", #call, hipGetErrorString(e__));              \
+            return (int)e__;                                                            \
+        }                                                                               \
+    } while (0)
+
+static inline int sbl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool sbl_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- wave-level reductions (64-wide wavefront; no LDS)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- counter-based RNG for dropout: one 32-bit draw per (seed, stream offset, element index).
+// The seed lives in device memory so a captured hipGraph draws fresh masks on every replay
+// (a one-thread kernel bumps it per step); fwd and bwd regenerate the same mask from it.
+__device__ __forceinline__ uint32_t sbl_rand_u32(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset + 1) + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// keep-decision with drop probability p: threshold = p * 2^32
+__device__ __forceinline__ bool sbl_keep(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t thresh) {
+    return sbl_rand_u32(seed, offset, idx) >= thresh;
+}
+static inline uint32_t sbl_drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}

@@ -1,0 +1,453 @@
+// frontend3D stem: Conv3d(1,64,(5,7,7),s(1,2,2),p(2,3,3)) -> BatchNorm3d -> ReLU -> MaxPool3d((1,3,3),s(1,2,2),p(0,1,1))
+// (SBL/transformer/video_frontend.py:99-104), forward and backward, channels-last output.
+//
+// conv fwd / wgrad are implicit GEMMs on v_mfma_f32_32x32x2_f32 with the (5 x 21 x 37) input patch of an
+// 8x16 output-pixel tile staged once in LDS (coalesced row reads of the (T,H,W) volume) and, for the forward,
+// all 64x245 weights resident in LDS for the lifetime of a persistent workgroup.  C_in = 1, so K = 245 taps.
+// Training BatchNorm needs the batch statistics before it can normalise: pass 1 writes conv_out and reduces
+// per-channel sum / sum-of-squares; pass 2 normalises + ReLU + pools (and records the pool argmax).  Backward is
+// two passes too: a reduction for the BN adjoint, then a weight-gradient GEMM whose A operand (dconv) is
+// recomputed on the fly from conv_out, the pooled gradient and the argmax — dconv is never materialised.
+#include "sbl_common.h"
+
+#define ST_TH 8
+#define ST_TW 16
+#define ST_PT 5
+#define ST_PH (2 * ST_TH + 5)   // 21
+#define ST_PW (2 * ST_TW + 5)   // 37
+#define ST_PWS 40               // padded patch row stride (floats)
+#define ST_PFS (ST_PH * ST_PWS) // 840: patch frame stride
+#define ST_K 245
+#define ST_KP 246               // K padded to a multiple of 2 (zero weight row)
+#define ST_WS 65                // weight row stride in LDS (floats): conflict-free transposed fill
+#define ST_DS 68                // dconv tile row stride in LDS
+
+__host__ __device__ constexpr int st_koff(int k) {
+    // LDS patch offset of tap k = (kt*7 + kh)*7 + kw; the pad tap 245 aliases tap 244 (its weight is 0)
+    return ((k < ST_K ? k : ST_K - 1) / 49) * ST_PFS + (((k < ST_K ? k : ST_K - 1) % 49) / 7) * ST_PWS +
+           ((k < ST_K ? k : ST_K - 1) % 7);
+}
+__host__ __device__ constexpr int st_pixoff(int pix) { return (pix >> 4) * 2 * ST_PWS + (pix & 15) * 2; }
+
+// Stage the zero-padded input patch of tile (img = n*T + t, ty, tx) into LDS.
+__device__ __forceinline__ void st_load_patch(float* patch, const float* __restrict__ x, int n, int t, int ty, int tx,
+                                              int T, int H, int W, int tid) {
+    const int ih0 = 2 * ty * ST_TH - 3, iw0 = 2 * tx * ST_TW - 3;
+    for (int i = tid; i < ST_PT * ST_PH * ST_PWS; i += 256) {
+        const int c = i % ST_PWS;
+        const int r = (i / ST_PWS) % ST_PH;
+        const int f = i / ST_PFS;
+        const int tt = t + f - 2, ih = ih0 + r, iw = iw0 + c;
+        float v = 0.f;
+        if (c < ST_PW && (unsigned)tt < (unsigned)T && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            v = x[(((long)n * T + tt) * H + ih) * W + iw];
+        patch[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ pass 1: conv + statistics
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ out, double* __restrict__ stats, int N,
+                                                            int T, int H, int W, int Ho, int Wo, int TY, int TX,
+                                                            int ntiles) {
+    __shared__ float Ws[ST_KP * ST_WS];
+    __shared__ float patch[ST_PT * ST_PFS];
+    float (*red)[128] = reinterpret_cast<float (*)[128]>(patch);   // reused after the tile loop: 80.8 KB total => 2 WG/CU
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+
+    for (int i = tid; i < 64 * ST_K; i += 256) {   // w[co][k] -> Ws[k][co]
+        const int co = i / ST_K, k = i - co * ST_K;
+        Ws[k * ST_WS + co] = w[i];
+    }
+    if (tid < 64) Ws[ST_K * ST_WS + tid] = 0.f;
+
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;      // this lane's A-operand pixel inside the tile
+    const int abase = py * 2 * ST_PWS + px * 2;
+    const float* wsb = Ws + half * ST_WS + l31;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % TX;
+        const int ty = (tile / TX) % TY;
+        const int img = tile / (TX * TY);
+        const int n = img / T, t = img - n * T;
+        __syncthreads();   // previous tile's patch reads done (also orders the Ws fill on the first trip)
+        st_load_patch(patch, x, n, t, ty, tx, T, H, W, tid);
+        __syncthreads();
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < ST_KP / 2; ++ks) {
+            const int off = half ? st_koff(2 * ks + 1) : st_koff(2 * ks);
+            const float a = patch[abase + off];
+            const float b0 = wsb[ks * 2 * ST_WS];
+            const float b1 = wsb[ks * 2 * ST_WS + 32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        // D: col (lane&31) = channel, row = pixel (r&3) + 8*(r>>2) + 4*half of this wave's 32 pixels
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oh = ty * ST_TH + 2 * wave + (m >> 4), ow = tx * ST_TW + (m & 15);
+            if (oh < Ho && ow < Wo) {
+                float* o = out + (((long)img * Ho + oh) * Wo + ow) * 64 + l31;
+                o[0] = acc0[r];
+                o[32] = acc1[r];
+                s1[0] += acc0[r];
+                s2[0] += acc0[r] * acc0[r];
+                s1[1] += acc1[r];
+                s2[1] += acc1[r] * acc1[r];
+            }
+        }
+    }
+    // block reduction of the statistics, then 128 double atomics per workgroup
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32, 64);
+        s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    __syncthreads();
+    if (half == 0) {
+        red[wave][l31] = s1[0];
+        red[wave][32 + l31] = s1[1];
+        red[wave][64 + l31] = s2[0];
+        red[wave][96 + l31] = s2[1];
+    }
+    __syncthreads();
+    if (tid < 128) atomicAdd(stats + tid, (double)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+}
+
+// ------------------------------------------------------------------ BN finalize (shared with the trunk)
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long count, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* save_mean, float* save_invstd,
+                                   int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c] / (double)count;
+    double var = stats[C + c] / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* mean,
+                                     float* invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rm[c];
+    invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+}
+
+// ------------------------------------------------------------------ pass 2: BN + ReLU + 3x3/2 max-pool
+// one thread = one pooled pixel x 4 channels; argmax = first maximum in (kh,kw) scan order with strict '>'
+// (torch's CPU max_pool3d tie-break), stored as kh*3+kw.
+__global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __restrict__ conv, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ pooled,
+                                                                uint8_t* __restrict__ argmax, int NT, int Ho, int Wo, int Hp,
+                                                                int Wp) {
+    const long total = (long)NT * Hp * Wp * 16;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i & 15) * 4;
+        long p = i >> 4;
+        const int pw = p % Wp;
+        p /= Wp;
+        const int ph = p % Hp;
+        const long img = p / Hp;
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c4);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bidx[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = 2 * ph - 1 + kh;
+            if ((unsigned)ih >= (unsigned)Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = 2 * pw - 1 + kw;
+                if ((unsigned)iw >= (unsigned)Wo) continue;
+                const float4 v = *reinterpret_cast<const float4*>(conv + ((img * Ho + ih) * Wo + iw) * 64 + c4);
+                float y[4];
+                y[0] = fmaxf((v.x - mu.x) * is.x * ga.x + be.x, 0.f);
+                y[1] = fmaxf((v.y - mu.y) * is.y * ga.y + be.y, 0.f);
+                y[2] = fmaxf((v.z - mu.z) * is.z * ga.z + be.z, 0.f);
+                y[3] = fmaxf((v.w - mu.w) * is.w * ga.w + be.w, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (y[q] > best[q]) {
+                        best[q] = y[q];
+                        bidx[q] = kh * 3 + kw;
+                    }
+            }
+        }
+        *reinterpret_cast<float4*>(pooled + (i >> 4) * 64 + c4) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uint32_t*>(argmax + (i >> 4) * 64 + c4) =
+            (uint32_t)bidx[0] | ((uint32_t)bidx[1] << 8) | ((uint32_t)bidx[2] << 16) | ((uint32_t)bidx[3] << 24);
+    }
+}
+
+// gradient w.r.t. the BN output at conv pixel (oh,ow), 4 channels: max-pool adjoint (gather over the <=4 windows
+// that contain the pixel, routed by the recorded argmax) times the ReLU mask (y > 0).
+__device__ __forceinline__ void stem_gather_g(const float* __restrict__ dpool, const uint8_t* __restrict__ argmax, long img,
+                                              int oh, int ow, int Hp, int Wp, int c4, const float y[4], float g[4]) {
+    g[0] = g[1] = g[2] = g[3] = 0.f;
+    const int ph_lo = oh >> 1, ph_hi = min(Hp - 1, (oh + 1) >> 1);
+    const int pw_lo = ow >> 1, pw_hi = min(Wp - 1, (ow + 1) >> 1);
+    for (int ph = ph_lo; ph <= ph_hi; ++ph)
+        for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+            const int pos = (oh - 2 * ph + 1) * 3 + (ow - 2 * pw + 1);
+            const long o = ((img * Hp + ph) * Wp + pw) * 64 + c4;
+            const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + o);
+            const float4 d = *reinterpret_cast<const float4*>(dpool + o);
+            if ((int)(am & 255) == pos) g[0] += d.x;
+            if ((int)((am >> 8) & 255) == pos) g[1] += d.y;
+            if ((int)((am >> 16) & 255) == pos) g[2] += d.z;
+            if ((int)(am >> 24) == pos) g[3] += d.w;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (!(y[q] > 0.f)) g[q] = 0.f;
+}
+
+// ------------------------------------------------------------------ backward pass 1: sum g, sum g*xhat
+__global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const float* __restrict__ conv, const float* __restrict__ dpool,
+                                                              const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, double* __restrict__ sums, int NT,
+                                                              int Ho, int Wo, int Hp, int Wp) {
+    __shared__ float red[16][16][8];
+    const int c4 = (threadIdx.x & 15) * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c4);
+    float sg[4] = {0, 0, 0, 0}, sgx[4] = {0, 0, 0, 0};
+    const long npix = (long)NT * Ho * Wo;
+    for (long p = blockIdx.x * 16L + (threadIdx.x >> 4); p < npix; p += (long)gridDim.x * 16) {
+        const int ow = p % Wo;
+        const long q = p / Wo;
+        const int oh = q % Ho;
+        const long img = q / Ho;
+        const float4 v = *reinterpret_cast<const float4*>(conv + p * 64 + c4);
+        float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
+        float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+        float g[4];
+        stem_gather_g(dpool, argmax, img, oh, ow, Hp, Wp, c4, y, g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sg[k] += g[k];
+            sgx[k] += g[k] * xh[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x >> 4][threadIdx.x & 15][k] = sg[k];
+        red[threadIdx.x >> 4][threadIdx.x & 15][4 + k] = sgx[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cq = threadIdx.x >> 3, k = threadIdx.x & 7;   // channel-quad, component
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r][cq][k];
+        const int ch = cq * 4 + (k & 3);
+        atomicAdd(sums + (k < 4 ? ch : 64 + ch), (double)s);
+    }
+}
+
+// ------------------------------------------------------------------ backward pass 2: weight gradient
+// dw[co][k] = sum_pixels dconv[pixel][co] * patch(pixel, k),  dconv = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
+// MFMA: rows = co (2 tiles), cols = k (8 tiles of 32, 245 valid), contraction over the tile's 128 pixels.
+// Wave w owns k-tiles {2w, 2w+1}; accumulators persist across the workgroup's tiles, float atomics at the end.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ conv,
+                                                         const float* __restrict__ dpool, const uint8_t* __restrict__ argmax,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const double* __restrict__ sums, float* __restrict__ dw,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int T,
+                                                         int H, int W, int Ho, int Wo, int Hp, int Wp, int TY, int TX,
+                                                         int ntiles) {
+    __shared__ __attribute__((aligned(16))) float Ds[128 * ST_DS];
+    __shared__ float patch[ST_PT * ST_PFS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const double cnt = (double)N * T * Ho * Wo;
+    if (blockIdx.x == 0 && tid < 64) {
+        dbeta[tid] = (float)sums[tid];
+        dgamma[tid] = (float)sums[64 + tid];
+    }
+    const int c4 = (tid & 15) * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c4);
+    float mg[4], mgx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mg[k] = (float)(sums[c4 + k] / cnt);
+        mgx[k] = (float)(sums[64 + c4 + k] / cnt);
+    }
+    const int k0 = (2 * wave) * 32 + l31, k1 = k0 + 32;   // this lane's two B-operand taps
+    const int koff0 = st_koff(k0), koff1 = st_koff(k1);
+
+    f32x16 acc[2][2];   // [co tile][k tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % TX;
+        const int ty = (tile / TX) % TY;
+        const int img = tile / (TX * TY);
+        const int n = img / T, t = img - n * T;
+        __syncthreads();
+        st_load_patch(patch, x, n, t, ty, tx, T, H, W, tid);
+        // dconv tile -> Ds[pixel][co]; thread = (pixel group, channel quad), 8 passes of 16 pixels
+#pragma unroll 2
+        for (int ps = 0; ps < 8; ++ps) {
+            const int pix = ps * 16 + (tid >> 4);
+            const int oh = ty * ST_TH + (pix >> 4), ow = tx * ST_TW + (pix & 15);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oh < Ho && ow < Wo) {
+                const float4 v = *reinterpret_cast<const float4*>(conv + (((long)img * Ho + oh) * Wo + ow) * 64 + c4);
+                float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
+                float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+                float g[4];
+                stem_gather_g(dpool, argmax, img, oh, ow, Hp, Wp, c4, y, g);
+                d.x = ga.x * is.x * (g[0] - mg[0] - xh[0] * mgx[0]);
+                d.y = ga.y * is.y * (g[1] - mg[1] - xh[1] * mgx[1]);
+                d.z = ga.z * is.z * (g[2] - mg[2] - xh[2] * mgx[2]);
+                d.w = ga.w * is.w * (g[3] - mg[3] - xh[3] * mgx[3]);
+            }
+            *reinterpret_cast<float4*>(&Ds[pix * ST_DS + c4]) = d;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int ps = 0; ps < 64; ++ps) {
+            const int pix = 2 * ps + half;
+            const int poff = st_pixoff(pix);
+            const float a0 = Ds[pix * ST_DS + l31];
+            const float a1 = Ds[pix * ST_DS + 32 + l31];
+            const float b0 = patch[poff + koff0];
+            const float b1 = patch[poff + koff1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // D: col (lane&31) = tap within the k tile, row = co within the co tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = (2 * wave + j) * 32 + l31;
+            if (k < ST_K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    atomicAdd(dw + co * ST_K + k, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------ host entry points
+static int stem_dims(const char* who, int N, int T, int H, int W) {
+    SBL_REQUIRE(N > 0 && T > 0 && H >= 8 && W >= 8 && H % 4 == 0 && W % 4 == 0, "%s: bad clip dims N=%d T=%d H=%d W=%d (H,W multiples of 4)", who, N, T, H, W);
+    SBL_REQUIRE((long)N * T * (H / 2) * (W / 2) * 64 < (1L << 40), "%s: too large", who);
+    return 0;
+}
+
+extern "C" int sbl_stem_conv_fwd(const float* x, const float* w, float* conv_out, double* stats, int N, int T, int H,
+                                 int W, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = stem_dims("sbl_stem_conv_fwd", N, T, H, W)) return e;
+    SBL_REQUIRE(x && w && conv_out && stats, "sbl_stem_conv_fwd: null pointer");
+    const int Ho = H / 2, Wo = W / 2, TY = sbl_cdiv(Ho, ST_TH), TX = sbl_cdiv(Wo, ST_TW);
+    const long ntiles = (long)N * T * TY * TX;
+    SBL_REQUIRE(ntiles < (1L << 31), "sbl_stem_conv_fwd: too many tiles");
+    SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 128, s));
+    const int grid = (int)(ntiles < 512 ? ntiles : 512);   // persistent: 2 workgroups per CU (LDS-bound)
+    hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(grid), dim3(256), 0, s, x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY,
+                       TX, (int)ntiles);
+    SBL_LAUNCH_CHECK("sbl_stem_conv_fwd");
+    return 0;
+}
+
+extern "C" int sbl_bn_finalize(const double* stats, long count, float* running_mean, float* running_var, float momentum,
+                               float eps, float* save_mean, float* save_invstd, int C, sbl_stream_t stream) {
+    SBL_REQUIRE(stats && save_mean && save_invstd && C > 0 && count > 0, "sbl_bn_finalize: bad args");
+    SBL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sbl_bn_finalize: running stats must both be set or both null");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sbl_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, count,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, C);
+    SBL_LAUNCH_CHECK("sbl_bn_finalize");
+    return 0;
+}
+extern "C" int sbl_bn_eval_stats(const float* rm, const float* rv, float eps, float* mean, float* invstd, int C,
+                                 sbl_stream_t stream) {
+    SBL_REQUIRE(rm && rv && mean && invstd && C > 0, "sbl_bn_eval_stats: bad args");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(sbl_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, rm, rv, eps, mean,
+                       invstd, C);
+    SBL_LAUNCH_CHECK("sbl_bn_eval_stats");
+    return 0;
+}
+
+extern "C" int sbl_stem_bn_relu_pool_fwd(const float* conv_out, const float* mean, const float* invstd, const float* gamma,
+                                         const float* beta, float* pooled, uint8_t* argmax, int NT, int Ho, int Wo,
+                                         sbl_stream_t stream) {
+    SBL_REQUIRE(conv_out && mean && invstd && gamma && beta && pooled && argmax, "sbl_stem_bn_relu_pool_fwd: null pointer");
+    SBL_REQUIRE(NT > 0 && Ho >= 2 && Wo >= 2 && Ho % 2 == 0 && Wo % 2 == 0, "sbl_stem_bn_relu_pool_fwd: bad dims %d %d %d", NT, Ho, Wo);
+    const int Hp = Ho / 2, Wp = Wo / 2;
+    const long total = (long)NT * Hp * Wp * 16;
+    const int grid = (int)(sbl_cdiv(total, 256) > 8192 ? 8192 : sbl_cdiv(total, 256));
+    hipLaunchKernelGGL(stem_bn_relu_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, conv_out, mean, invstd,
+                       gamma, beta, pooled, argmax, NT, Ho, Wo, Hp, Wp);
+    SBL_LAUNCH_CHECK("sbl_stem_bn_relu_pool_fwd");
+    return 0;
+}
+
+extern "C" int sbl_stem_bwd_reduce(const float* conv_out, const float* dpooled, const uint8_t* argmax, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, double* sums, int NT, int Ho,
+                                   int Wo, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(conv_out && dpooled && argmax && mean && invstd && gamma && beta && sums, "sbl_stem_bwd_reduce: null pointer");
+    SBL_REQUIRE(NT > 0 && Ho >= 2 && Wo >= 2 && Ho % 2 == 0 && Wo % 2 == 0, "sbl_stem_bwd_reduce: bad dims");
+    SBL_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 128, s));
+    const long npix = (long)NT * Ho * Wo;
+    const int grid = (int)(sbl_cdiv(npix, 16) > 4096 ? 4096 : sbl_cdiv(npix, 16));
+    hipLaunchKernelGGL(stem_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, conv_out, dpooled, argmax, mean, invstd, gamma,
+                       beta, sums, NT, Ho, Wo, Ho / 2, Wo / 2);
+    SBL_LAUNCH_CHECK("sbl_stem_bwd_reduce");
+    return 0;
+}
+
+extern "C" int sbl_stem_wgrad(const float* x, const float* conv_out, const float* dpooled, const uint8_t* argmax,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              const double* sums, float* dw, float* dgamma, float* dbeta, int N, int T, int H, int W,
+                              sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = stem_dims("sbl_stem_wgrad", N, T, H, W)) return e;
+    SBL_REQUIRE(x && conv_out && dpooled && argmax && mean && invstd && gamma && beta && sums && dw && dgamma && dbeta,
+                "sbl_stem_wgrad: null pointer");
+    const int Ho = H / 2, Wo = W / 2, TY = sbl_cdiv(Ho, ST_TH), TX = sbl_cdiv(Wo, ST_TW);
+    const long ntiles = (long)N * T * TY * TX;
+    SBL_REQUIRE(ntiles < (1L << 31), "sbl_stem_wgrad: too many tiles");
+    SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 64 * ST_K, s));
+    const int grid = (int)(ntiles < 768 ? ntiles : 768);   // 3 workgroups per CU (52 KB LDS each)
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, conv_out, dpooled, argmax, mean, invstd, gamma,
+                       beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles);
+    SBL_LAUNCH_CHECK("sbl_stem_wgrad");
+    return 0;
+}

@@ -1,0 +1,719 @@
+"""torch.autograd Functions over the C ABI of libsbl_hip.so.
+
+torch is plumbing only here: it owns device memory (caching allocator), the
+current HIP stream and the autograd tape; every FLOP of forward and backward runs
+in a hand-written HIP kernel reached through sbl_for_multilingual_lip_reading_amd._lib.call().
+Nothing in this file falls back to torch math on failure: a missing library or a
+non-zero status raises.
+
+All Functions are hipGraph-capturable: no host sync, no host read of device data;
+dropout seeds and teacher-forcing coins live in device memory.
+"""
+import torch
+
+try:
+    from . import _lib
+except ImportError:      # drop-in mode: this directory itself is on sys.path
+    import _lib
+
+call = _lib.call
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SblHipError("sbl ops need CUDA/HIP tensors (got a %s tensor); there is no CPU path" % t.device)
+
+
+def _rows(t):
+    """(M, ld) of a 2-D fp32 tensor whose last dim is dense."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32, (t.shape, t.stride(), t.dtype)
+    return t.size(0), (t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1)))
+
+
+# --------------------------------------------------------------------------- #
+# dropout state: one device-resident seed shared by every mask of a step
+# --------------------------------------------------------------------------- #
+class DropoutState:
+    """Device seed + per-call-site offsets.  `next_offset()` hands out a distinct
+    stream offset per dropout site per forward; `bump()` advances the seed on the
+    device (one tiny kernel), so a captured graph draws new masks on every replay."""
+
+    def __init__(self, device, seed=0x5B1C0FFEE):
+        self.seed = torch.tensor([seed], dtype=torch.int64, device=device)
+        self._offset = 0
+
+    def next_offset(self):
+        self._offset += 1
+        return self._offset
+
+    def begin_step(self):
+        self._offset = 0
+        call("sbl_seed_bump", _p(self.seed), _s())
+
+
+_dropout_states = {}
+
+
+def dropout_state(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _dropout_states.get(key)
+    if st is None:
+        st = _dropout_states[key] = DropoutState(device)
+    return st
+
+
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, relu=0, mask=None, ldm=0, accumulate=0):
+    call("sbl_gemm_f32", ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), relu, _p(mask), ldm,
+         accumulate, _s())
+
+
+# --------------------------------------------------------------------------- #
+# Linear
+# --------------------------------------------------------------------------- #
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (optional ReLU).  nn.Linear: attention.py:16-18,27; module.py:42-43; encoder.py:27;
+    decoder.py:59-60."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        _need_cuda(x, w, b)
+        M, ldx = _rows(x)
+        N, K = w.shape
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        gemm(0, 1, M, N, K, x, ldx, w, K, y, N, bias=b, relu=int(relu))
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias = b is not None
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy * (y > 0).to(dy.dtype)
+        M, ldx = _rows(x)
+        N, K = w.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            gemm(0, 0, M, K, N, dy, N, w, K, dx, K)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+            gemm(1, 0, N, K, M, dy, N, x, ldx, dw, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, device=dy.device, dtype=torch.float32)
+            call("sbl_colsum_f32", _p(dy), N, _p(db), M, N, 0, _s())
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, relu=False):
+    shp = x.shape
+    x2 = x if x.dim() == 2 else x.reshape(-1, shp[-1])
+    y = LinearFn.apply(x2, w, b, relu)
+    return y if x.dim() == 2 else y.view(*shp[:-1], w.size(0))
+
+
+# --------------------------------------------------------------------------- #
+# dropout / PE / LayerNorm
+# --------------------------------------------------------------------------- #
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _need_cuda(x)
+        x = x.contiguous()
+        st = dropout_state(x.device)
+        ctx.off = st.next_offset()
+        ctx.p = p
+        ctx.seed = st.seed
+        y = torch.empty_like(x)
+        call("sbl_dropout", _p(x), _p(y), x.numel(), p, _p(st.seed), ctx.off, _s())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call("sbl_dropout", _p(dy), _p(dx), dy.numel(), ctx.p, _p(ctx.seed), ctx.off, _s())
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p))
+
+
+class AddPEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pe):
+        _need_cuda(x, pe)
+        B, L, D = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call("sbl_add_pe", _p(x), _p(pe), _p(y), B, L, D, _s())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + res); encoder.py:54 (res=None), attention.py:58, module.py:51."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        _need_cuda(x, gamma, beta)
+        D = x.size(-1)
+        x2 = x.contiguous().view(-1, D)
+        r2 = None if res is None else res.contiguous().view(-1, D)
+        M = x2.size(0)
+        y = torch.empty_like(x2)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        call("sbl_add_layernorm_fwd", _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _s())
+        ctx.save_for_backward(x2, r2, gamma, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, gamma, mean, rstd = ctx.saved_tensors
+        D = x2.size(1)
+        M = x2.size(0)
+        dy2 = dy.contiguous().view(-1, D)
+        dz = torch.empty_like(dy2)
+        dg = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        call("sbl_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dg), _p(db),
+             M, D, _s())
+        dz = dz.view(ctx.shape)
+        return dz, (dz if r2 is not None else None), dg, db, None
+
+
+class RowScaleFn(torch.autograd.Function):
+    """x * non_pad_mask (mask: (..., 1) float, one factor per row); encoder.py:86,89."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        _need_cuda(x, scale)
+        x = x.contiguous()
+        sc = scale.to(torch.float32).contiguous().view(-1)
+        D = x.size(-1)
+        assert sc.numel() == x.numel() // D
+        y = torch.empty_like(x)
+        call("sbl_rowscale", _p(x), _p(sc), _p(y), sc.numel(), D, _s())
+        ctx.save_for_backward(sc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (sc,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call("sbl_rowscale", _p(dy), _p(sc), _p(dx), sc.numel(), dy.size(-1), _s())
+        return dx, None
+
+
+def add_layernorm(x, res, gamma, beta, eps=1e-5):
+    return AddLayerNormFn.apply(x, res, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------- #
+# attention core (used by ScaledDotProductAttention directly)
+# --------------------------------------------------------------------------- #
+def _mask_args(mask, B, Lq, Lk):
+    """mask: None | 'causal' | uint8/bool tensor (B,Lq,Lk) -> (kind, tensor-or-None)"""
+    if mask is None:
+        return 0, None
+    if isinstance(mask, str):
+        assert mask == "causal"
+        return 1, None
+    m = mask
+    if m.dim() == 3 and m.size(0) != B:            # head-repeated (n_head*B, Lq, Lk): attention.py:50
+        m = m[:B]
+    m = m.expand(B, Lq, Lk).to(torch.uint8).contiguous()
+    return 2, m
+
+
+class SDPAFn(torch.autograd.Function):
+    """softmax(Q K^T * scale, masked) [dropout] V over (B, L, H*64) views; attention.py:72-83."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, scale, mask_kind, mask_t, drop_p):
+        _need_cuda(q, k, v)
+        B, Lq, _ = q.shape
+        Lk = k.size(1)
+        assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+        assert q.stride(0) == Lq * q.stride(1) and k.stride(0) == Lk * k.stride(1) and v.stride(0) == Lk * v.stride(1)
+        o = torch.empty(B, Lq, H * 64, device=q.device, dtype=torch.float32)
+        p = torch.empty(H * B, Lq, Lk, device=q.device, dtype=torch.float32)
+        seed, off = None, 0
+        if drop_p > 0:
+            st = dropout_state(q.device)
+            seed, off = st.seed, st.next_offset()
+        call("sbl_attention_fwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), H * 64, _p(p),
+             mask_kind, _p(mask_t), B, H, Lq, Lk, scale, drop_p, _p(seed), off, _s())
+        ctx.save_for_backward(q, k, v, p, seed)
+        ctx.cfg = (H, scale, drop_p, off)
+        ctx.mark_non_differentiable(p)
+        return o, p
+
+    @staticmethod
+    def backward(ctx, do, _dp):
+        q, k, v, p, seed = ctx.saved_tensors
+        H, scale, drop_p, off = ctx.cfg
+        B, Lq, _ = q.shape
+        Lk = k.size(1)
+        do = do.contiguous()
+        dq = torch.empty(B, Lq, H * 64, device=q.device, dtype=torch.float32)
+        dk = torch.empty(B, Lk, H * 64, device=q.device, dtype=torch.float32)
+        dv = torch.empty(B, Lk, H * 64, device=q.device, dtype=torch.float32)
+        call("sbl_attention_bwd", _p(do), H * 64, _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(p),
+             _p(dq), H * 64, _p(dk), H * 64, _p(dv), H * 64, B, H, Lq, Lk, scale, drop_p, _p(seed), off, _s())
+        return dq, dk, dv, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# fused multi-head attention sub-layer
+# --------------------------------------------------------------------------- #
+def _adjacent(*ts):
+    """True if the tensors are contiguous and laid out back to back in memory (rows of one fused matrix)."""
+    p = ts[0].data_ptr()
+    for t in ts:
+        if not t.is_contiguous() or t.data_ptr() != p:
+            return False
+        p += t.numel() * t.element_size()
+    return True
+
+
+class KVProjectFn(torch.autograd.Function):
+    """[K | V] = x [Wk; Wv]^T + [bk; bv] -> (B*Lk, 2*H*64).  For decoder cross-attention this is hoisted out
+    of the 16-step loop (step-invariant: SURVEY 3.2 consequence ii).  Wk/Wv (and bk/bv) must be adjacent rows of
+    one fused buffer (MultiHeadAttention keeps them that way)."""
+
+    @staticmethod
+    def forward(ctx, x2, wk, bk, wv, bv):
+        _need_cuda(x2, wk, wv)
+        assert _adjacent(wk, wv) and _adjacent(bk, bv)
+        M, ldx = _rows(x2)
+        N2, K = 2 * wk.size(0), wk.size(1)
+        kv = torch.empty(M, N2, device=x2.device, dtype=torch.float32)
+        gemm(0, 1, M, N2, K, x2, ldx, wk, K, kv, N2, bias=bk)
+        ctx.save_for_backward(x2, wk, wv)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        x2, wk, wv = ctx.saved_tensors
+        dkv = dkv.contiguous()
+        M, ldx = _rows(x2)
+        N2, K = 2 * wk.size(0), wk.size(1)
+        dx = torch.empty(M, K, device=dkv.device, dtype=torch.float32)
+        gemm(0, 0, M, K, N2, dkv, N2, wk, K, dx, K)
+        dw = torch.empty(N2, K, device=dkv.device, dtype=torch.float32)
+        gemm(1, 0, N2, K, M, dkv, N2, x2, ldx, dw, K)
+        db = torch.empty(N2, device=dkv.device, dtype=torch.float32)
+        call("sbl_colsum_f32", _p(dkv), N2, _p(db), M, N2, 0, _s())
+        h = N2 // 2
+        return dx, dw[:h], db[:h], dw[h:], db[h:]
+
+
+class MHAFn(torch.autograd.Function):
+    """One whole MultiHeadAttention.forward (attention.py:32-60) as a single tape node:
+    projections -> attention core -> fc -> dropout -> LayerNorm(out + residual).
+
+    self_attn=True : q, k, v all come from x through ONE fused (M x 3*H*64) GEMM.
+    self_attn=False: q from x, [K|V] given pre-projected (kv, shape (B*Lk, 2*H*64)).
+    """
+
+    @staticmethod
+    def forward(ctx, x, kv, wq, bq, wk, bk, wv, bv, wfc, bfc, gamma, beta, H, mask_kind, mask_t, drop_p, eps):
+        _need_cuda(x, wq, wfc)
+        B, Lq, D = x.shape
+        x2 = x.contiguous().view(B * Lq, D)
+        M = B * Lq
+        HD = H * 64
+        dev = x.device
+        self_attn = kv is None
+        if self_attn:
+            assert _adjacent(wq, wk, wv) and _adjacent(bq, bk, bv)
+            qkv = torch.empty(M, 3 * HD, device=dev, dtype=torch.float32)
+            gemm(0, 1, M, 3 * HD, D, x2, D, wq, D, qkv, 3 * HD, bias=bq)
+            qp, kp, vp = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
+            ldq = ldk = ldv = 3 * HD
+            Lk = Lq
+        else:
+            qkv = torch.empty(M, HD, device=dev, dtype=torch.float32)
+            gemm(0, 1, M, HD, D, x2, D, wq, D, qkv, HD, bias=bq)
+            Lk = kv.size(0) // B
+            qp, kp, vp = qkv, kv, kv[:, HD:]
+            ldq, ldk, ldv = HD, 2 * HD, 2 * HD
+        att = torch.empty(M, HD, device=dev, dtype=torch.float32)
+        p = torch.empty(H * B, Lq, Lk, device=dev, dtype=torch.float32)
+        seed, off_a, off_o = None, 0, 0
+        if drop_p > 0:
+            st = dropout_state(dev)
+            seed, off_a, off_o = st.seed, st.next_offset(), st.next_offset()
+        call("sbl_attention_fwd", _p(qp), ldq, _p(kp), ldk, _p(vp), ldv, _p(att), HD, _p(p), mask_kind, _p(mask_t), B, H,
+             Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
+        o = torch.empty(M, D, device=dev, dtype=torch.float32)
+        gemm(0, 1, M, D, HD, att, HD, wfc, HD, o, D, bias=bfc)
+        if drop_p > 0:
+            call("sbl_dropout", _p(o), _p(o), M * D, drop_p, _p(seed), off_o, _s())
+        y = torch.empty(M, D, device=dev, dtype=torch.float32)
+        mean = torch.empty(M, device=dev, dtype=torch.float32)
+        rstd = torch.empty(M, device=dev, dtype=torch.float32)
+        call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _s())
+        ctx.save_for_backward(x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed)
+        ctx.cfg = (B, Lq, Lk, D, H, drop_p, off_a, off_o, self_attn)
+        ctx.mark_non_differentiable(p)
+        return y.view(B, Lq, D), p
+
+    @staticmethod
+    def backward(ctx, dy, _dp):
+        x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed = ctx.saved_tensors
+        B, Lq, Lk, D, H, drop_p, off_a, off_o, self_attn = ctx.cfg
+        M, HD, dev = B * Lq, H * 64, dy.device
+        dy2 = dy.contiguous().view(M, D)
+        # LayerNorm(o + x) adjoint -> dz (gradient of both o and the residual x)
+        dz = torch.empty(M, D, device=dev, dtype=torch.float32)
+        dgamma = torch.zeros(D, device=dev, dtype=torch.float32)
+        dbeta = torch.zeros(D, device=dev, dtype=torch.float32)
+        call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
+             _p(dbeta), M, D, _s())
+        do = dz
+        if drop_p > 0:
+            do = torch.empty_like(dz)
+            call("sbl_dropout", _p(dz), _p(do), M * D, drop_p, _p(seed), off_o, _s())
+        # fc
+        dwfc = torch.empty(D, HD, device=dev, dtype=torch.float32)
+        gemm(1, 0, D, HD, M, do, D, att, HD, dwfc, HD)
+        dbfc = torch.empty(D, device=dev, dtype=torch.float32)
+        call("sbl_colsum_f32", _p(do), D, _p(dbfc), M, D, 0, _s())
+        datt = torch.empty(M, HD, device=dev, dtype=torch.float32)
+        gemm(0, 0, M, HD, D, do, D, wfc, HD, datt, HD)
+        # attention core
+        if self_attn:
+            dqkv = torch.empty(M, 3 * HD, device=dev, dtype=torch.float32)
+            qp, kp, vp = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
+            ld = 3 * HD
+            call("sbl_attention_bwd", _p(datt), HD, _p(qp), ld, _p(kp), ld, _p(vp), ld, _p(p), _p(dqkv), ld,
+                 _p(dqkv[:, HD:]), ld, _p(dqkv[:, 2 * HD:]), ld, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
+            dw = torch.empty(3 * HD, D, device=dev, dtype=torch.float32)
+            gemm(1, 0, 3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D)
+            db = torch.empty(3 * HD, device=dev, dtype=torch.float32)
+            call("sbl_colsum_f32", _p(dqkv), 3 * HD, _p(db), M, 3 * HD, 0, _s())
+            dx = dz          # residual branch gradient; the projection's input gradient accumulates on top
+            gemm(0, 0, M, D, 3 * HD, dqkv, 3 * HD, wq, D, dx, D, accumulate=1)
+            return (dx.view(B, Lq, D), None, dw[:HD], db[:HD], dw[HD:2 * HD], db[HD:2 * HD], dw[2 * HD:], db[2 * HD:],
+                    dwfc, dbfc, dgamma, dbeta, None, None, None, None, None)
+        dq = torch.empty(M, HD, device=dev, dtype=torch.float32)
+        dkv = torch.empty(B * Lk, 2 * HD, device=dev, dtype=torch.float32)
+        call("sbl_attention_bwd", _p(datt), HD, _p(qkv), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(p), _p(dq), HD,
+             _p(dkv), 2 * HD, _p(dkv[:, HD:]), 2 * HD, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
+        dwq = torch.empty(HD, D, device=dev, dtype=torch.float32)
+        gemm(1, 0, HD, D, M, dq, HD, x2, D, dwq, D)
+        dbq = torch.empty(HD, device=dev, dtype=torch.float32)
+        call("sbl_colsum_f32", _p(dq), HD, _p(dbq), M, HD, 0, _s())
+        dx = dz
+        gemm(0, 0, M, D, HD, dq, HD, wq, D, dx, D, accumulate=1)
+        return (dx.view(B, Lq, D), dkv, dwq, dbq, None, None, None, None, dwfc, dbfc, dgamma, dbeta,
+                None, None, None, None, None)
+
+
+class FFNFn(torch.autograd.Function):
+    """PositionwiseFeedForward.forward (module.py:47-52) as one tape node:
+    LayerNorm(dropout(relu(x W1^T + b1) W2^T + b2) + x)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, drop_p, eps):
+        _need_cuda(x, w1, w2)
+        shp = x.shape
+        D = shp[-1]
+        x2 = x.contiguous().view(-1, D)
+        M, F_, dev = x2.size(0), w1.size(0), x.device
+        h = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        gemm(0, 1, M, F_, D, x2, D, w1, D, h, F_, bias=b1, relu=1)
+        o = torch.empty(M, D, device=dev, dtype=torch.float32)
+        gemm(0, 1, M, D, F_, h, F_, w2, F_, o, D, bias=b2)
+        seed, off = None, 0
+        if drop_p > 0:
+            st = dropout_state(dev)
+            seed, off = st.seed, st.next_offset()
+            call("sbl_dropout", _p(o), _p(o), M * D, drop_p, _p(seed), off, _s())
+        y = torch.empty(M, D, device=dev, dtype=torch.float32)
+        mean = torch.empty(M, device=dev, dtype=torch.float32)
+        rstd = torch.empty(M, device=dev, dtype=torch.float32)
+        call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _s())
+        ctx.save_for_backward(x2, h, o, mean, rstd, w1, w2, gamma, seed)
+        ctx.cfg = (shp, drop_p, off)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, o, mean, rstd, w1, w2, gamma, seed = ctx.saved_tensors
+        shp, drop_p, off = ctx.cfg
+        M, D = x2.shape
+        F_, dev = w1.size(0), dy.device
+        dy2 = dy.contiguous().view(M, D)
+        dz = torch.empty(M, D, device=dev, dtype=torch.float32)
+        dgamma = torch.zeros(D, device=dev, dtype=torch.float32)
+        dbeta = torch.zeros(D, device=dev, dtype=torch.float32)
+        call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
+             _p(dbeta), M, D, _s())
+        do = dz
+        if drop_p > 0:
+            do = torch.empty_like(dz)
+            call("sbl_dropout", _p(dz), _p(do), M * D, drop_p, _p(seed), off, _s())
+        dw2 = torch.empty(D, F_, device=dev, dtype=torch.float32)
+        gemm(1, 0, D, F_, M, do, D, h, F_, dw2, F_)
+        db2 = torch.empty(D, device=dev, dtype=torch.float32)
+        call("sbl_colsum_f32", _p(do), D, _p(db2), M, D, 0, _s())
+        dh = torch.empty(M, F_, device=dev, dtype=torch.float32)
+        gemm(0, 0, M, F_, D, do, D, w2, F_, dh, F_, mask=h, ldm=F_)      # ReLU adjoint fused in the epilogue
+        dw1 = torch.empty(F_, D, device=dev, dtype=torch.float32)
+        gemm(1, 0, F_, D, M, dh, F_, x2, D, dw1, D)
+        db1 = torch.empty(F_, device=dev, dtype=torch.float32)
+        call("sbl_colsum_f32", _p(dh), F_, _p(db1), M, F_, 0, _s())
+        dx = dz
+        gemm(0, 0, M, D, F_, dh, F_, w1, D, dx, D, accumulate=1)
+        return dx.view(shp), dw1, db1, dw2, db2, dgamma, dbeta, None, None
+
+
+# --------------------------------------------------------------------------- #
+# decoder pieces
+# --------------------------------------------------------------------------- #
+class EmbedPEFn(torch.autograd.Function):
+    """emb[tok] + pe[:L]; decoder.py:116-120 (x_logit_scale = 1)."""
+
+    @staticmethod
+    def forward(ctx, tok, L, emb, pe):
+        _need_cuda(tok, emb, pe)
+        B = tok.size(0)
+        V, D = emb.shape
+        out = torch.empty(B, L, D, device=emb.device, dtype=torch.float32)
+        call("sbl_embed_pe_fwd", _p(tok), tok.stride(0), _p(emb), _p(pe), _p(out), B, L, D, V, _s())
+        # tokens are written in place by later steps, but positions < L never change again
+        ctx.tok, ctx.L, ctx.shape = tok, L, (V, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        V, D = ctx.shape
+        dy = dy.contiguous()
+        demb = torch.zeros(V, D, device=dy.device, dtype=torch.float32)
+        call("sbl_embed_bwd", _p(ctx.tok), ctx.tok.stride(0), _p(dy), _p(demb), dy.size(0), ctx.L, D, V, _s())
+        return None, None, demb, None
+
+
+class FusionFn(torch.autograd.Function):
+    """A' = A + flip(B), B' = 2B + flip(A); decoder.py:132-143,160-164 (closed form)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_cuda(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        B, L, D = a.shape
+        a2, b2 = torch.empty_like(a), torch.empty_like(b)
+        call("sbl_fusion_fwd", _p(a), _p(b), _p(a2), _p(b2), B, L, D, _s())
+        return a2, b2
+
+    @staticmethod
+    def backward(ctx, da2, db2):
+        da2, db2 = da2.contiguous(), db2.contiguous()
+        B, L, D = da2.shape
+        da, db = torch.empty_like(da2), torch.empty_like(db2)
+        call("sbl_fusion_bwd", _p(da2), _p(db2), _p(da), _p(db), B, L, D, _s())
+        return da, db
+
+
+def argmax_select(pred, gold, ys, step, use_argmax, coins_dev=None):
+    """ys[:, step+1] = argmax(pred) if coin else gold[:, step]; decoder.py:173-186, on the device."""
+    B, V = pred.shape
+    call("sbl_argmax_select", _p(pred), pred.stride(0), _p(gold), 0 if gold is None else gold.stride(0), _p(ys),
+         ys.stride(0), step, int(use_argmax), _p(coins_dev), B, V, _s())
+
+
+class SmoothedCEFn(torch.autograd.Function):
+    """cal_loss (loss.py:27-52): returns (mean loss over gold != ignore, stats[3] = (sum, n_valid, n_correct))."""
+
+    @staticmethod
+    def forward(ctx, pred, gold, eps, ignore_id):
+        _need_cuda(pred, gold)
+        pred = pred.contiguous()
+        gold = gold.contiguous()
+        R, C = pred.shape
+        out3 = torch.empty(3, device=pred.device, dtype=torch.float32)
+        call("sbl_smoothed_ce_fwd", _p(pred), _p(gold), _p(out3), R, C, eps, ignore_id, _s())
+        ctx.save_for_backward(pred, gold, out3)
+        ctx.cfg = (eps, ignore_id)
+        ctx.mark_non_differentiable(out3)
+        return out3[0] / out3[1], out3
+
+    @staticmethod
+    def backward(ctx, gloss, _g3):
+        pred, gold, out3 = ctx.saved_tensors
+        eps, ignore_id = ctx.cfg
+        R, C = pred.shape
+        gs = gloss.reshape(1).to(torch.float32).contiguous()
+        dpred = torch.empty_like(pred)
+        call("sbl_smoothed_ce_bwd", _p(pred), _p(gold), _p(out3), _p(gs), _p(dpred), R, C, eps, ignore_id, _s())
+        return dpred, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# visual frontend
+# --------------------------------------------------------------------------- #
+class StemFn(torch.autograd.Function):
+    """frontend3D (video_frontend.py:99-104) on (N,T,H,W) clips -> pooled NHWC (N*T, H/4, W/4, 64)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, momentum, eps):
+        _need_cuda(x, w, gamma, beta)
+        x = x.contiguous()
+        N, T, H, W = x.shape
+        dev = x.device
+        Ho, Wo = H // 2, W // 2
+        w2 = w.contiguous().view(64, 245)
+        conv = torch.empty(N * T, Ho, Wo, 64, device=dev, dtype=torch.float32)
+        stats = torch.empty(128, device=dev, dtype=torch.float64)
+        call("sbl_stem_conv_fwd", _p(x), _p(w2), _p(conv), _p(stats), N, T, H, W, _s())
+        mean = torch.empty(64, device=dev, dtype=torch.float32)
+        invstd = torch.empty(64, device=dev, dtype=torch.float32)
+        if training:
+            call("sbl_bn_finalize", _p(stats), N * T * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps, _p(mean),
+                 _p(invstd), 64, _s())
+        else:
+            call("sbl_bn_eval_stats", _p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), 64, _s())
+        pooled = torch.empty(N * T, Ho // 2, Wo // 2, 64, device=dev, dtype=torch.float32)
+        argmax = torch.empty(N * T, Ho // 2, Wo // 2, 64, device=dev, dtype=torch.uint8)
+        call("sbl_stem_bn_relu_pool_fwd", _p(conv), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(pooled), _p(argmax),
+             N * T, Ho, Wo, _s())
+        ctx.save_for_backward(x, conv, argmax, mean, invstd, gamma, beta)
+        ctx.training = training
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, conv, argmax, mean, invstd, gamma, beta = ctx.saved_tensors
+        if not ctx.training:
+            raise _lib.SblHipError("stem backward is implemented for training-mode BatchNorm (batch statistics) only")
+        N, T, H, W = x.shape
+        dev = x.device
+        dpooled = dpooled.contiguous()
+        sums = torch.empty(128, device=dev, dtype=torch.float64)
+        call("sbl_stem_bwd_reduce", _p(conv), _p(dpooled), _p(argmax), _p(mean), _p(invstd), _p(gamma), _p(beta),
+             _p(sums), N * T, H // 2, W // 2, _s())
+        dw = torch.empty(64, 245, device=dev, dtype=torch.float32)
+        dgamma = torch.empty(64, device=dev, dtype=torch.float32)
+        dbeta = torch.empty(64, device=dev, dtype=torch.float32)
+        call("sbl_stem_wgrad", _p(x), _p(conv), _p(dpooled), _p(argmax), _p(mean), _p(invstd), _p(gamma), _p(beta),
+             _p(sums), _p(dw), _p(dgamma), _p(dbeta), N, T, H, W, _s())
+        return None, dw.view(64, 1, 5, 7, 7), dgamma, dbeta, None, None, None, None, None
+
+
+class ConvBNFn(torch.autograd.Function):
+    """conv (3x3 pad 1 | 1x1 pad 0, bias-free) -> BatchNorm2d -> [+ residual] -> [ReLU] on NHWC activations;
+    video_frontend.py:28-41,69-71.  The BN batch statistics are reduced in the conv epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, relu, stride, training, momentum, eps):
+        _need_cuda(x, w, gamma, beta)
+        x = x.contiguous()
+        NIMG, H, W, Cin = x.shape
+        Cout, _, KH, KW = w.shape
+        pad = 1 if KH == 3 else 0
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        dev = x.device
+        w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+        call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), None, Cout, Cin, KH, KW, _s())
+        conv = torch.empty(NIMG, Ho, Wo, Cout, device=dev, dtype=torch.float32)
+        mean = torch.empty(Cout, device=dev, dtype=torch.float32)
+        invstd = torch.empty(Cout, device=dev, dtype=torch.float32)
+        if training:
+            stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), _p(stats), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+            call("sbl_bn_finalize", _p(stats), NIMG * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps, _p(mean),
+                 _p(invstd), Cout, _s())
+        else:
+            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), None, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+            call("sbl_bn_eval_stats", _p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), Cout, _s())
+        y = torch.empty_like(conv)
+        r = None if res is None else res.contiguous()
+        call("sbl_bn_apply_fwd", _p(conv), _p(r), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), NIMG * Ho * Wo, Cout,
+             int(relu), _s())
+        ctx.save_for_backward(x, w, conv, y if relu else None, mean, invstd, gamma)
+        ctx.cfg = (relu, stride, pad, training, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, conv, y, mean, invstd, gamma = ctx.saved_tensors
+        relu, stride, pad, training, has_res = ctx.cfg
+        if not training:
+            raise _lib.SblHipError("ConvBN backward is implemented for training-mode BatchNorm only")
+        NIMG, H, W, Cin = x.shape
+        Cout, _, KH, KW = w.shape
+        dev = x.device
+        dy = dy.contiguous()
+        rows = conv.numel() // Cout
+        sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+        call("sbl_bn_bwd_reduce", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(sums), rows, Cout, int(relu), _s())
+        dconv = torch.empty_like(conv)
+        dres = torch.empty_like(conv) if has_res else None
+        dgamma = torch.empty(Cout, device=dev, dtype=torch.float32)
+        dbeta = torch.empty(Cout, device=dev, dtype=torch.float32)
+        call("sbl_bn_bwd_apply", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dconv), _p(dres),
+             _p(dgamma), _p(dbeta), rows, Cout, int(relu), _s())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+            w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
+            call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
+            dx = torch.empty_like(x)
+            call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+        dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+        call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+        dw = torch.empty_like(w)
+        call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(dw), Cout, Cin, KH, KW, _s())
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) + view on NHWC; video_frontend.py:87-88."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        NIMG, H, W, C = x.shape
+        y = torch.empty(NIMG, C, device=x.device, dtype=torch.float32)
+        call("sbl_avgpool_fwd", _p(x), _p(y), NIMG, H * W, C, _s())
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        NIMG, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        call("sbl_avgpool_bwd", _p(dy), _p(dx), NIMG, H * W, C, _s())
+        return dx
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """Fused Adam over flat fp32 buffers (SBL/train.py:75; optimizer.py:18-27)."""
+    _need_cuda(p, g, m, v)
+    call("sbl_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _s())

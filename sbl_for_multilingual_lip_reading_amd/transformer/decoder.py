@@ -1,0 +1,187 @@
+"""Mirror of SBL_Multilingual_Lip_reading/transformer/decoder.py (the SBL bidirectional decoder)."""
+import random
+
+import torch
+import torch.nn as nn
+
+from ._env import config, ops
+from .attention import MultiHeadAttention
+from .module import PositionalEncoding, PositionwiseFeedForward
+from .utils import get_attn_key_pad_mask, get_attn_pad_mask, get_non_pad_mask, get_subsequent_mask, pad_list
+
+IGNORE_ID = config.IGNORE_ID
+
+
+class Decoder(nn.Module):
+    ''' A decoder model with self attention mechanism (decoder.py:16-191, 301-385).
+
+    Same constructor / forward / recognize_beam signatures and state-dict keys as the reference.  What differs
+    is how the same numbers are produced:
+      * the cross-attention K/V projections of the encoder output are computed once per layer per forward, not
+        once per step (step-invariant; exact algebra);
+      * the aliased in-place fusion loops are one kernel, A' = A + flip(B), B' = 2B + flip(A);
+      * tokens, argmax and the teacher-forcing select stay on the device (no host sync in the 16-step loop);
+        the coin itself is still `random.random() > 0.5`, one draw per step, so `random.seed(k)` reproduces the
+        reference's choices.  Set `self.coins_dev` to a device int32 tensor of 16 flags to take the coins from
+        device memory instead (hipGraph replay).
+    '''
+
+    def __init__(
+            self, sos_id, eos_id,
+            n_tgt_vocab, d_word_vec,
+            n_layers, n_head, d_k, d_v,
+            d_model, d_inner, dropout=0.1,
+            tgt_emb_prj_weight_sharing=True,
+            pe_maxlen=5000):
+        super(Decoder, self).__init__()
+        self.sos_id = sos_id  # Start of Sentence
+        self.eos_id = eos_id  # End of Sentence
+        self.n_tgt_vocab = n_tgt_vocab
+
+        self.d_word_vec = d_word_vec
+        self.n_layers = n_layers
+        self.n_head = n_head
+        self.d_k = d_k
+        self.d_v = d_v
+        self.d_model = d_model
+        self.d_inner = d_inner
+        self.tgt_emb_prj_weight_sharing = tgt_emb_prj_weight_sharing   # stored, ignored (decoder.py:40)
+        self.pe_maxlen = pe_maxlen
+
+        self.tgt_word_emb = nn.Embedding(n_tgt_vocab, d_word_vec)
+        self.positional_encoding = PositionalEncoding(d_model, max_len=pe_maxlen)
+        self.dropout = nn.Dropout(dropout)
+
+        self.layer_first_l2r = DecoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout)
+        self.layer_stack_l2r = nn.ModuleList([
+            DecoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout)
+            for _ in range(self.n_layers - 1)])
+
+        self.layer_first_r2l = DecoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout)
+        self.layer_stack_r2l = nn.ModuleList([
+            DecoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout)
+            for _ in range(self.n_layers - 1)])
+
+        self.x_logit_scale = 1.
+        # 58 = 56 + <sos> + <eos>; hard-coded like decoder.py:59-60
+        self.tgt_word_prj_l2r = nn.Linear(512, 58, bias=False)
+        self.tgt_word_prj_r2l = nn.Linear(512, 58, bias=False)
+
+        self.coins_dev = None      # optional device int32[16]: 1 = feed own argmax (graph replay)
+        self.last_coins = None     # the coins of the last forward (host list), for inspection / parity tests
+
+    def preprocess(self, padded_input):
+        """Generate decoder input and output label from padded_input (decoder.py:62-77): strip IGNORE_ID,
+        add <sos> / <eos>, pad both to 16 with *eos*.  Vectorised on the input's device, no host sync."""
+        N, To = padded_input.shape
+        maxlen = config.MAX_DECODE_LEN
+        valid = padded_input.ne(IGNORE_ID)
+        # stable compaction of the valid ids to the left (the reference's y[y != IGNORE_ID])
+        order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
+        comp = torch.gather(padded_input, 1, order)
+        n_valid = valid.sum(1, keepdim=True)
+        pos = torch.arange(To, device=padded_input.device).unsqueeze(0)
+        comp = torch.where(pos < n_valid, comp, torch.full_like(comp, self.eos_id))
+        ys_in_pad = padded_input.new_full((N, maxlen), self.eos_id)
+        ys_out_pad = padded_input.new_full((N, maxlen), self.eos_id)
+        ys_in_pad[:, 0] = self.sos_id
+        w = min(To, maxlen - 1)
+        ys_in_pad[:, 1:1 + w] = comp[:, :w]
+        ys_out_pad[:, :min(To, maxlen)] = comp[:, :maxlen]
+        assert ys_in_pad.size() == ys_out_pad.size()
+        return ys_in_pad, ys_out_pad
+
+    def _layers(self, direction):
+        first = self.layer_first_l2r if direction == 0 else self.layer_first_r2l
+        stack = self.layer_stack_l2r if direction == 0 else self.layer_stack_r2l
+        return [first] + list(stack)
+
+    def _run(self, encoder_outputs, gold_l2r, gold_r2l, teacher_mode):
+        """The 16-step loop shared by forward (decoder.py:106-186) and recognize_beam (:310-383)."""
+        maxlen = config.MAX_DECODE_LEN
+        N = encoder_outputs.size(0)
+        dev = encoder_outputs.device
+        layers = (self._layers(0), self._layers(1))
+        # hoisted cross-attention K/V (one GEMM per layer per direction per forward)
+        kv = [[lay.enc_attn.project_kv(encoder_outputs) for lay in layers[d]] for d in (0, 1)]
+        ys = [torch.full((N, maxlen + 1), self.eos_id, dtype=torch.long, device=dev) for _ in (0, 1)]
+        for y in ys:
+            y[:, 0] = self.sos_id
+        emb = self.tgt_word_emb.weight
+        pe = self.positional_encoding.pe[0]
+        heads = (self.tgt_word_prj_l2r.weight, self.tgt_word_prj_r2l.weight)
+        golds = (gold_l2r, gold_r2l)
+        outs = ([], [])
+        coins = []
+        for i in range(maxlen):
+            L = i + 1
+            x = [ops.dropout(ops.EmbedPEFn.apply(ys[d], L, emb, pe), self.dropout.p, self.training) for d in (0, 1)]
+            for n in range(self.n_layers):
+                slf_mask = 'causal' if n == 0 else None       # decoder.py:123-125 vs :150,:157
+                for d in (0, 1):
+                    x[d], _, _ = layers[d][n](x[d], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[d][n])
+                x[0], x[1] = ops.FusionFn.apply(x[0], x[1])
+            preds = [ops.linear(x[d][:, -1], heads[d]) for d in (0, 1)]
+            outs[0].append(preds[0])
+            outs[1].append(preds[1])
+            if teacher_mode:
+                if self.coins_dev is not None:
+                    own = 0
+                else:
+                    own = int(random.random() > config.TEACHER_COIN_THRESHOLD)   # decoder.py:176
+                    coins.append(bool(own))
+            else:
+                own = 1
+            for d in (0, 1):
+                ops.argmax_select(preds[d].detach(), golds[d], ys[d], i, own,
+                                  self.coins_dev if teacher_mode else None)
+        self.last_coins = coins
+        return outs, ys
+
+    def forward(self, padded_input_l2r, padded_input_r2l, encoder_outputs,
+                encoder_input_lengths, return_attns=False):
+        """
+        Args:
+            padded_input: N x To
+            encoder_padded_outputs: N x Ti x H
+        Returns: (pred_l2r (N,16,58), gold_l2r (N,16), pred_r2l, gold_r2l)
+        """
+        dev = encoder_outputs.device
+        ys_in_pad_l2r, ys_out_pad_l2r = self.preprocess(padded_input_l2r.to(dev))
+        ys_in_pad_r2l, ys_out_pad_r2l = self.preprocess(padded_input_r2l.to(dev))
+        outs, _ = self._run(encoder_outputs, ys_out_pad_l2r, ys_out_pad_r2l, teacher_mode=True)
+        return torch.stack(outs[0], 1), ys_out_pad_l2r, torch.stack(outs[1], 1), ys_out_pad_r2l
+
+    def recognize_beam(self, encoder_outputs):
+        """Greedy decode, always own argmax (decoder.py:301-385).  Returns (ys_l2r, ys_r2l) (N,17) int64."""
+        with torch.no_grad():
+            _, ys = self._run(encoder_outputs, None, None, teacher_mode=False)
+        return ys[0], ys[1]
+
+
+class DecoderLayer(nn.Module):
+    ''' Compose with three layers (decoder.py:387-408) '''
+
+    def __init__(self, d_model, d_inner, n_head, d_k, d_v, dropout=0.1):
+        super(DecoderLayer, self).__init__()
+        self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def forward(self, dec_input, enc_output, non_pad_mask=None, slf_attn_mask=None, dec_enc_attn_mask=None,
+                enc_kv=None):
+        dec_output, dec_slf_attn = self.slf_attn(
+            dec_input, dec_input, dec_input, mask=slf_attn_mask)
+        if non_pad_mask is not None:
+            dec_output = ops.RowScaleFn.apply(dec_output, non_pad_mask)
+
+        dec_output, dec_enc_attn = self.enc_attn(
+            dec_output, enc_output, enc_output, mask=dec_enc_attn_mask, kv_proj=enc_kv)
+        if non_pad_mask is not None:
+            dec_output = ops.RowScaleFn.apply(dec_output, non_pad_mask)
+
+        dec_output = self.pos_ffn(dec_output)
+        if non_pad_mask is not None:
+            dec_output = ops.RowScaleFn.apply(dec_output, non_pad_mask)
+
+        return dec_output, dec_slf_attn, dec_enc_attn
