@@ -39,12 +39,19 @@ int sbl_abi_version(void);
  * C[M,N] (+)= opA(A)[M,K] * opB(B)[K,N], row-major; opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k],
  * opB(B)[k,n] = transB ? B[n*ldb+k] : B[k*ldb+n].  Epilogue: +bias[n], ReLU, or multiply by
  * (relu_mask[m*ldm+n] > 0) (ReLU backward fused into the producing GEMM).
- * accumulate: 0 = overwrite, 1 = C += (in place).
+ * accumulate: 0 = overwrite, 1 = C += (in place: gradients accumulate straight into the flat .grad buffer).
+ * a_colsum (transA=1 only, may be NULL): float[M] += sum_k opA(A)[m,k], float atomics — the bias gradient
+ *   db = sum_rows dY rides on the weight-gradient GEMM dW = dY^T X.
+ * ws / ws_bytes (may be NULL/0): split-K workspace = int[4096] tile counters (zero on first hand-over, left
+ *   zero by every call) followed by fp32 partial slabs.  With it, small-M problems split K across workgroups
+ *   and the last-arriving workgroup of each tile reduces the slabs and runs the epilogue inside the same
+ *   launch; without it split-K falls back to float atomics on C (plain epilogue only).  One workspace per
+ *   stream: concurrent calls must not share it.
  * Replaces nn.Linear forward/backward: SBL/transformer/attention.py:16-18,27,41-43,57;
  * module.py:42-43,49; encoder.py:27,54; decoder.py:59-60,166-167. */
 int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                  float* C, long ldc, const float* bias, int relu, const float* relu_mask, long ldm, int accumulate,
-                 sbl_stream_t stream);
+                 float* a_colsum, void* ws, long ws_bytes, sbl_stream_t stream);
 /* out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
 int sbl_colsum_f32(const float* X, long ldx, float* out, int M, int N, int accumulate, sbl_stream_t stream);
 
@@ -114,12 +121,16 @@ int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream);
 
 /* ---------------------------------------------------------------- LayerNorm with fused residual
  * y = LN(x + res) * gamma + beta (eps 1e-5), rows of D=512: attention.py:58, module.py:51, encoder.py:54. */
+/* With drop_p > 0 the sub-layer's dropout is fused: y = LN(dropout(x) + res) (attention.py:57-58,
+ * module.py:50-51); the mask is a function of (*seed, offset, element index). */
 int sbl_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                          float* mean, float* rstd, int M, int D, float eps, sbl_stream_t stream);
-/* dz (= dx = dres); dgamma/dbeta accumulated with float atomics (caller zeroes or accumulates) */
+                          float* mean, float* rstd, int M, int D, float eps, float drop_p, const uint64_t* seed,
+                          uint64_t offset, sbl_stream_t stream);
+/* dz = gradient of the LayerNorm input (= dres); dx_drop (may be NULL) = gradient of the pre-dropout x;
+ * dgamma/dbeta accumulated with float atomics (caller zeroes, or passes the .grad buffers to accumulate) */
 int sbl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
-                          const float* rstd, float* dz, float* dgamma, float* dbeta, int M, int D,
-                          sbl_stream_t stream);
+                          const float* rstd, float* dz, float* dx_drop, float* dgamma, float* dbeta, int M, int D,
+                          float drop_p, const uint64_t* seed, uint64_t offset, sbl_stream_t stream);
 /* y = x + pe[l] (l = row % L) : encoder.py:53-55 positional add */
 int sbl_add_pe(const float* x, const float* pe, float* y, int B, int L, int D, sbl_stream_t stream);
 

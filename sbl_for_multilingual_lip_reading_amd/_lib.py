@@ -11,7 +11,7 @@ P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 
 # name -> argtypes (all return int); mirrors include/sbl_hip.h one to one
 SIGNATURES = {
-    "sbl_gemm_f32": [I, I, I, I, I, P, L, P, L, P, L, P, I, P, L, I, P],
+    "sbl_gemm_f32": [I, I, I, I, I, P, L, P, L, P, L, P, I, P, L, I, P, P, L, P],
     "sbl_colsum_f32": [P, L, P, I, I, I, P],
     "sbl_stem_conv_fwd": [P, P, P, P, I, I, I, I, P],
     "sbl_stem_bn_relu_pool_fwd": [P, P, P, P, P, P, P, I, I, I, P],
@@ -31,8 +31,8 @@ SIGNATURES = {
     "sbl_avgpool_bwd": [P, P, I, I, I, P],
     "sbl_dropout": [P, P, L, F, P, U64, P],
     "sbl_seed_bump": [P, P],
-    "sbl_add_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, P],
-    "sbl_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
+    "sbl_add_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, F, P, U64, P],
+    "sbl_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, P, U64, P],
     "sbl_add_pe": [P, P, P, I, I, I, P],
     "sbl_rowscale": [P, P, P, L, I, P],
     "sbl_attention_fwd": [P, L, P, L, P, L, P, L, P, I, P, I, I, I, I, F, F, P, U64, P],

@@ -15,78 +15,95 @@ extern "C" const char* sbl_last_error(void) { return g_err; }
 extern "C" int sbl_abi_version(void) { return SBL_ABI_VERSION; }
 
 // ------------------------------------------------------------------ dispatch
-template <class AL, class BL, int BM, int BN>
+template <class AL, class BL, int BM, int BN, int KU>
 static void launch_mode(const AL& al, const BL& bl, float* C, long ldc, const float* bias, int relu,
-                        const float* relu_mask, long ldm, int mode, int M, int N, int K, int splits, hipStream_t s) {
+                        const float* relu_mask, long ldm, int mode, int M, int N, int K, int splits, SplitCtl sc,
+                        hipStream_t s) {
     if (mode == 0) {
         EpiStore<0, false> e{C, ldc, bias, relu, nullptr, relu_mask, ldm};
-        sbl_launch_gemm<AL, BL, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s);
+        sbl_launch_gemm<AL, BL, EpiStore<0, false>, BM, BN, KU>(al, bl, e, M, N, K, splits, s, sc);
     } else if (mode == 1) {
         EpiStore<1, false> e{C, ldc, bias, relu, nullptr, relu_mask, ldm};
-        sbl_launch_gemm<AL, BL, EpiStore<1, false>, BM, BN>(al, bl, e, M, N, K, 1, s);
+        sbl_launch_gemm<AL, BL, EpiStore<1, false>, BM, BN, KU>(al, bl, e, M, N, K, splits, s, sc);
     } else {
         EpiStore<2, false> e{C, ldc, nullptr, 0, nullptr, nullptr, 0};
-        sbl_launch_gemm<AL, BL, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s);
+        sbl_launch_gemm<AL, BL, EpiStore<2, false>, BM, BN, KU>(al, bl, e, M, N, K, splits, s, sc);
     }
 }
 
-template <bool VEC, int BM, int BN>
+template <bool VEC, int BM, int BN, int KU>
 static void launch_trans(int transA, int transB, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                          const float* bias, int relu, const float* relu_mask, long ldm, int mode, int M, int N, int K,
-                         int splits, hipStream_t s) {
+                         int splits, SplitCtl sc, hipStream_t s) {
     if (!transA && transB) {
         DenseKC<BM, VEC> al{A, lda, M};
         DenseKC<BN, VEC> bl{B, ldb, N};
-        launch_mode<DenseKC<BM, VEC>, DenseKC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+        launch_mode<DenseKC<BM, VEC>, DenseKC<BN, VEC>, BM, BN, KU>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s);
     } else if (!transA && !transB) {
         DenseKC<BM, VEC> al{A, lda, M};
         DenseMC<BN, VEC> bl{B, ldb, N};
-        launch_mode<DenseKC<BM, VEC>, DenseMC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+        launch_mode<DenseKC<BM, VEC>, DenseMC<BN, VEC>, BM, BN, KU>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s);
     } else if (transA && !transB) {
         DenseMC<BM, VEC> al{A, lda, M};
         DenseMC<BN, VEC> bl{B, ldb, N};
-        launch_mode<DenseMC<BM, VEC>, DenseMC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+        launch_mode<DenseMC<BM, VEC>, DenseMC<BN, VEC>, BM, BN, KU>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s);
     } else {
         DenseMC<BM, VEC> al{A, lda, M};
         DenseKC<BN, VEC> bl{B, ldb, N};
-        launch_mode<DenseMC<BM, VEC>, DenseKC<BN, VEC>, BM, BN>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s);
+        launch_mode<DenseMC<BM, VEC>, DenseKC<BN, VEC>, BM, BN, KU>(al, bl, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s);
     }
 }
 
+#define SBL_WS_COUNTERS 4096   // ints at the head of the workspace, one per output tile
+
 extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
                             long ldb, float* C, long ldc, const float* bias, int relu, const float* relu_mask, long ldm,
-                            int accumulate, sbl_stream_t stream) {
+                            int accumulate, float* a_colsum, void* ws, long ws_bytes, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     SBL_REQUIRE(M > 0 && N > 0 && K > 0, "sbl_gemm_f32: non-positive dims M=%d N=%d K=%d", M, N, K);
     SBL_REQUIRE(A && B && C, "sbl_gemm_f32: null operand");
     SBL_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                 "sbl_gemm_f32: leading dimension too small (lda=%ld ldb=%ld ldc=%ld)", lda, ldb, ldc);
     SBL_REQUIRE(!relu_mask || ldm >= N, "sbl_gemm_f32: ldm=%ld < N=%d", ldm, N);
+    SBL_REQUIRE(!a_colsum || transA, "sbl_gemm_f32: a_colsum needs transA=1 (A stored [K][M])");
+    SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_WS_COUNTERS), "sbl_gemm_f32: workspace unaligned or < 16 KiB");
     // float4 path: every row start 16-byte aligned and, for k-contiguous operands, K % 4 == 0
     bool vec = sbl_aligned16(A) && sbl_aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (!transA || transB) vec = vec && (K % 4 == 0);
     const bool plain = !bias && !relu && !relu_mask;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
     const bool big = (M >= 1024 && N >= 256 && tiles64 >= 2048);
+    // split K when the output has too few 64x64 tiles to fill 256 CUs: aim at ~256 workgroups, chunks of at
+    // least one 64-deep macro step, at most 8 slices (the last-arriving workgroup reads every slab)
     int splits = 1;
-    if (plain && !big && tiles64 < 256 && K >= 256) {
-        splits = (int)((512 + tiles64 - 1) / tiles64);
+    if (!big && tiles64 < 192 && K >= 128) {
+        splits = (int)((256 + tiles64 - 1) / tiles64);
         if (splits > K / 64) splits = K / 64;
+        if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
     }
+    SplitCtl sc{nullptr, nullptr, a_colsum};
     int mode = accumulate ? 1 : 0;
     if (splits > 1) {
-        mode = 2;
-        if (!accumulate) SBL_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
+        const long need = (long)sizeof(int) * SBL_WS_COUNTERS + tiles64 * splits * (long)(64 * 64 * sizeof(float));
+        if (ws && tiles64 <= SBL_WS_COUNTERS && need <= ws_bytes) {
+            sc.counters = (int*)ws;                                     // in-launch slab reduction, full epilogue
+            sc.slabs = (float*)((char*)ws + sizeof(int) * SBL_WS_COUNTERS);
+        } else if (plain) {
+            mode = 2;                                                   // no workspace: float atomics on C
+            if (!accumulate) SBL_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s));
+        } else {
+            splits = 1;
+        }
     }
-#define SBL_GO(VEC, BM, BN) \
-    launch_trans<VEC, BM, BN>(transA, transB, A, lda, B, ldb, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, s)
+#define SBL_GO(VEC, BM, BN, KU) \
+    launch_trans<VEC, BM, BN, KU>(transA, transB, A, lda, B, ldb, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s)
     if (big) {
-        if (vec) SBL_GO(true, 128, 128);
-        else SBL_GO(false, 128, 128);
+        if (vec) SBL_GO(true, 128, 128, 1);
+        else SBL_GO(false, 128, 128, 1);
     } else {
-        if (vec) SBL_GO(true, 64, 64);
-        else SBL_GO(false, 64, 64);
+        if (vec) SBL_GO(true, 64, 64, 4);
+        else SBL_GO(false, 64, 64, 1);
     }
 #undef SBL_GO
     SBL_LAUNCH_CHECK("sbl_gemm_f32");

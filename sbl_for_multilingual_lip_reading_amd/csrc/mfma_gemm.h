@@ -25,6 +25,7 @@
 // Dense, k-contiguous: element (r,k) at p[r*ld + k].  Used for X[M,K] and W[N,K] of Linear.
 template <int BR, bool VEC>
 struct DenseKC {
+    static constexpr bool kColSum = false;
     const float* p;
     long ld;
     int rows;
@@ -63,6 +64,8 @@ struct DenseKC {
             r.v[ps] = v;
         }
     }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
     __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
 #pragma unroll
         for (int ps = 0; ps < BR / 64; ++ps) {
@@ -79,6 +82,7 @@ struct DenseKC {
 // GEMMs and for W[K,N] in input-gradient GEMMs.
 template <int BR, bool VEC>
 struct DenseMC {
+    static constexpr bool kColSum = true;
     const float* p;
     long ld;
     int rows;
@@ -114,6 +118,13 @@ struct DenseMC {
             r.v[ps] = v;
         }
     }
+    __device__ __forceinline__ void accum(const Regs& r, float4& cs) const {   // column sums over k of this operand
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            cs.x += r.v[ps].x; cs.y += r.v[ps].y; cs.z += r.v[ps].z; cs.w += r.v[ps].w;
+        }
+    }
+    __device__ __forceinline__ int col(const State& s) const { return s.c; }
     __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
@@ -157,6 +168,7 @@ __device__ __forceinline__ bool conv_src_coord(const ConvGeom& g, int oh, int ow
 // so one BK slice never straddles a tap and each lane's float4 stays inside one pixel.
 template <int BR, bool DGRAD>
 struct ConvGatherKC {
+    static constexpr bool kColSum = false;
     const float* p;
     ConvGeom g;
     int rows;   // NIMG*OH*OW
@@ -195,6 +207,8 @@ struct ConvGatherKC {
             r.v[ps] = v;
         }
     }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
     __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
 #pragma unroll
         for (int ps = 0; ps < BR / 64; ++ps) {
@@ -211,6 +225,7 @@ struct ConvGatherKC {
 // GEMM-row r = (kh,kw,c) with c fastest; a lane's 4 consecutive r share one tap (C % 4 == 0).
 template <int BR>
 struct ConvGatherMC {
+    static constexpr bool kColSum = false;
     const float* p;
     ConvGeom g;
     int rows;   // KH*KW*C
@@ -251,6 +266,8 @@ struct ConvGatherMC {
             r.v[ps] = v;
         }
     }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
     __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
@@ -296,10 +313,31 @@ struct EpiStore {
 };
 
 // ------------------------------------------------------------------ kernel
-template <class AL, class BL, class EPI, int BM, int BN>
-__global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, int M, int N, int K, int kchunk) {
-    __shared__ __attribute__((aligned(16))) float As[2][SBL_BK][BM + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SBL_BK][BN + 4];
+// Split-K control.  When gridDim.z > 1 and `slabs` is set, every K-slice workgroup stores its partial tile to
+// its slab, publishes it (agent-scope release) and draws a ticket from the tile's counter; the workgroup that
+// draws the last ticket acquires, sums the slabs in slice order (deterministic) and runs the full epilogue
+// (bias / ReLU / += ...), then re-arms the counter.  One launch, no memset, no atomics on C; placement- and
+// dispatch-order independent (cdna_hip_programming.md, Guideline 16 counter form).  Counters must be zero when
+// the workspace is first handed over; they are left zero by every launch.
+// `a_colsum`: optional [M] vector receiving sum_k A(m,k) via float atomics (the bias gradient rides on the
+// weight-gradient GEMM's A = dY^T operand); only loaders with kColSum (DenseMC) feed it.
+struct SplitCtl {
+    float* slabs;
+    int* counters;
+    float* a_colsum;
+};
+
+// KU = BK-deep sub-tiles staged per barrier ("macro step" = KU*16 of K).  KU = 1 for the big, occupancy-rich
+// problems (trunk convolutions: 3 workgroups per CU hide the load latency); KU = 4 for the decoder's skinny
+// GEMMs, which run ~1 workgroup per CU and are bound by the global-load latency of each barrier-to-barrier
+// step: 4x the bytes in flight per step, 4x fewer exposed latencies and barriers.
+template <class AL, class BL, class EPI, int BM, int BN, int KU>
+__global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
+                                                            int kchunk) {
+    constexpr int MK = KU * SBL_BK;   // macro step
+    __shared__ __attribute__((aligned(16))) float As[2][MK][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][MK][BN + 4];
+    __shared__ int s_last;
     constexpr int TM = BM / 64, TN = BN / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -309,10 +347,12 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
 
     typename AL::State sa;
     typename BL::State sb;
-    typename AL::Regs ra;
-    typename BL::Regs rb;
+    typename AL::Regs ra[KU];
+    typename BL::Regs rb[KU];
     al.init(sa, m0, tid);
     bl.init(sb, n0, tid);
+    const bool do_colsum = AL::kColSum && sc.a_colsum != nullptr && blockIdx.y == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -322,24 +362,34 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    al.load(sa, kbeg, kend, ra);
-    bl.load(sb, kbeg, kend, rb);
-    al.store(As[0], sa, ra, tid);
-    bl.store(Bs[0], sb, rb, tid);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        al.load(sa, kbeg + u * SBL_BK, kend, ra[u]);
+        bl.load(sb, kbeg + u * SBL_BK, kend, rb[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        if (do_colsum) al.accum(ra[u], cs);
+        al.store(&As[0][u * SBL_BK], sa, ra[u], tid);
+        bl.store(&Bs[0][u * SBL_BK], sb, rb[u], tid);
+    }
     __syncthreads();
 
     const int arow = wm * (BM / 2) + (lane & 31);
     const int brow = wn * (BN / 2) + (lane & 31);
     const int kh = lane >> 5;
     int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += SBL_BK) {
-        const bool has_next = (k0 + SBL_BK) < kend;
+    for (int k0 = kbeg; k0 < kend; k0 += MK) {
+        const bool has_next = (k0 + MK) < kend;
         if (has_next) {
-            al.load(sa, k0 + SBL_BK, kend, ra);
-            bl.load(sb, k0 + SBL_BK, kend, rb);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                al.load(sa, k0 + MK + u * SBL_BK, kend, ra[u]);
+                bl.load(sb, k0 + MK + u * SBL_BK, kend, rb[u]);
+            }
         }
 #pragma unroll
-        for (int ks = 0; ks < SBL_BK / 2; ++ks) {
+        for (int ks = 0; ks < MK / 2; ++ks) {
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[cur][2 * ks + kh][arow + i * 32];
@@ -352,11 +402,68 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (has_next) {
-            al.store(As[cur ^ 1], sa, ra, tid);
-            bl.store(Bs[cur ^ 1], sb, rb, tid);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (do_colsum) al.accum(ra[u], cs);
+                al.store(&As[cur ^ 1][u * SBL_BK], sa, ra[u], tid);
+                bl.store(&Bs[cur ^ 1][u * SBL_BK], sb, rb[u], tid);
+            }
         }
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (do_colsum) {
+        const int c = al.col(sa);
+        if (c + 0 < M) atomicAdd(sc.a_colsum + c + 0, cs.x);
+        if (c + 1 < M) atomicAdd(sc.a_colsum + c + 1, cs.y);
+        if (c + 2 < M) atomicAdd(sc.a_colsum + c + 2, cs.z);
+        if (c + 3 < M) atomicAdd(sc.a_colsum + c + 3, cs.w);
+    }
+
+    // in-launch split-K reduction (last-arriving workgroup of each tile)
+    if (gridDim.z > 1 && sc.slabs != nullptr) {
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const int nz = gridDim.z;
+        float* mine = sc.slabs + ((long)tile * nz + blockIdx.z) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: hipcc may drop the fence's own wait
+            const int t = __hip_atomic_fetch_add(sc.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == nz - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(sc.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const float* base = sc.slabs + (long)tile * nz * (BM * BN) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int z = 0; z < nz; ++z) {      // slice order: deterministic sum; 16 independent loads per slice
+                    const float* q = base + (long)z * (BM * BN) + (i * TN + j) * 16 * 256;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = q[r * 256];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
+                }
+            }
     }
 
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -377,11 +484,12 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     }
 }
 
-template <class AL, class BL, class EPI, int BM, int BN>
+template <class AL, class BL, class EPI, int BM, int BN, int KU = 1>
 static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int splits,
-                                   hipStream_t s) {
-    int kchunk = sbl_cdiv(sbl_cdiv(K, splits), SBL_BK) * SBL_BK;
+                                   hipStream_t s, SplitCtl sc = SplitCtl{nullptr, nullptr, nullptr}) {
+    constexpr int MK = KU * SBL_BK;
+    int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN>), grid, dim3(256), 0, s, al, bl, epi, M, N, K, kchunk);
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk);
 }

@@ -205,7 +205,9 @@ extern "C" int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream) {
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ y, float* __restrict__ mean,
-                                                                float* __restrict__ rstd, int M, float eps) {
+                                                                float* __restrict__ rstd, int M, float eps, uint32_t thresh,
+                                                                float keep_scale, const uint64_t* __restrict__ seed,
+                                                                uint64_t offset) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -213,6 +215,14 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
     float v[8];
     *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + o + lane * 4);
     *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(x + o + 256 + lane * 4);
+    if (thresh) {   // fused dropout on x (same element indexing as dropout_kernel: mask is regenerated in backward)
+        const uint64_t sd = *seed;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t idx = (uint64_t)o + (k < 4 ? 0 : 256) + lane * 4 + (k & 3);
+            v[k] = sbl_keep(sd, offset, idx, thresh) ? v[k] * keep_scale : 0.f;
+        }
+    }
     if (res) {
         const float4 r0 = *reinterpret_cast<const float4*>(res + o + lane * 4);
         const float4 r1 = *reinterpret_cast<const float4*>(res + o + 256 + lane * 4);
@@ -247,9 +257,12 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ res, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                float* __restrict__ dz, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int M, int rows_per_block) {
+                                                                float* __restrict__ dz, float* __restrict__ dx_drop,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                                int rows_per_block, uint32_t thresh, float keep_scale,
+                                                                const uint64_t* __restrict__ seed, uint64_t offset) {
     __shared__ float red[4][2][512];
+    const uint64_t sd = thresh ? *seed : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 4), g1 = *reinterpret_cast<const float4*>(gamma + 256 + lane * 4);
     const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -261,6 +274,15 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         float v[8], d[8];
         *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + o + lane * 4);
         *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(x + o + 256 + lane * 4);
+        bool keep[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            keep[k] = true;
+            if (thresh) {
+                keep[k] = sbl_keep(sd, offset, (uint64_t)o + (k < 4 ? 0 : 256) + lane * 4 + (k & 3), thresh);
+                v[k] = keep[k] ? v[k] * keep_scale : 0.f;
+            }
+        }
         if (res) {
             const float4 q0 = *reinterpret_cast<const float4*>(res + o + lane * 4);
             const float4 q1 = *reinterpret_cast<const float4*>(res + o + 256 + lane * 4);
@@ -287,6 +309,12 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         for (int k = 0; k < 8; ++k) out[k] = rs * (ga[k] * d[k] - s1 - xh[k] * s2);
         *reinterpret_cast<float4*>(dz + o + lane * 4) = *reinterpret_cast<float4*>(out);
         *reinterpret_cast<float4*>(dz + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
+        if (dx_drop) {   // gradient w.r.t. the pre-dropout x
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[k] = keep[k] ? out[k] * keep_scale : 0.f;
+            *reinterpret_cast<float4*>(dx_drop + o + lane * 4) = *reinterpret_cast<float4*>(out);
+            *reinterpret_cast<float4*>(dx_drop + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -302,27 +330,35 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
 }
 
 extern "C" int sbl_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                                     float* mean, float* rstd, int M, int D, float eps, sbl_stream_t stream) {
+                                     float* mean, float* rstd, int M, int D, float eps, float drop_p,
+                                     const uint64_t* seed, uint64_t offset, sbl_stream_t stream) {
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_add_layernorm_fwd: bad dropout args");
     SBL_REQUIRE(D == 512, "sbl_add_layernorm_fwd: D=%d (only d_model=512 is built: optimizer.py:8, decoder.py:59)", D);
     SBL_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0, "sbl_add_layernorm_fwd: bad args");
     SBL_REQUIRE(sbl_aligned16(x) && sbl_aligned16(y) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma) && sbl_aligned16(beta), "sbl_add_layernorm_fwd: unaligned");
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(sbl_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                       beta, y, mean, rstd, M, eps);
+                       beta, y, mean, rstd, M, eps, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed,
+                       offset);
     SBL_LAUNCH_CHECK("sbl_add_layernorm_fwd");
     return 0;
 }
 
 extern "C" int sbl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
-                                     const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta, int M,
-                                     int D, sbl_stream_t stream) {
+                                     const float* mean, const float* rstd, float* dz, float* dx_drop, float* dgamma,
+                                     float* dbeta, int M, int D, float drop_p, const uint64_t* seed, uint64_t offset,
+                                     sbl_stream_t stream) {
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_add_layernorm_bwd: bad dropout args");
+    SBL_REQUIRE(!dx_drop || sbl_aligned16(dx_drop), "sbl_add_layernorm_bwd: dx_drop unaligned");
     SBL_REQUIRE(D == 512, "sbl_add_layernorm_bwd: D=%d", D);
     SBL_REQUIRE(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && M > 0, "sbl_add_layernorm_bwd: bad args");
     SBL_REQUIRE(sbl_aligned16(dy) && sbl_aligned16(x) && sbl_aligned16(dz) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma), "sbl_add_layernorm_bwd: unaligned");
-    int blocks = sbl_cdiv(M, 16);
-    if (blocks > 256) blocks = 256;
+    // few, fat workgroups: each ends with 1024 float atomics on the same dgamma/dbeta words
+    int blocks = sbl_cdiv(M, 32);
+    if (blocks > 64) blocks = 64;
     const int rpb = sbl_cdiv(M, blocks);
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(sbl_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, x, res,
-                       gamma, mean, rstd, dz, dgamma, dbeta, M, rpb);
+                       gamma, mean, rstd, dz, dx_drop, dgamma, dbeta, M, rpb, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
+                       1.f / (1.f - drop_p), seed, offset);
     SBL_LAUNCH_CHECK("sbl_add_layernorm_bwd");
     return 0;
 }

@@ -73,6 +73,9 @@ class FlatModel:
                     self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                     p.data = self.flat_param[off:off + n].view(p.shape)
                     p.grad = self.flat_grad[off:off + n].view(p.shape)
+                    # ops.* backward kernels accumulate straight into this buffer (GEMM '+=' epilogues, atomics)
+                    # and hand autograd None, so no AccumulateGrad add kernels run for these parameters
+                    p._sbl_grad = p.grad
                     off += pad(n)
                 self.ranges[seg] = (start, off)
         self.numel = total
@@ -102,23 +105,24 @@ class GradientExchange:
             self._install()
 
     def _install(self):
-        model, flat = self.flat.model, self.flat
-        names = {n: p for n, p in model.named_parameters()}
-        # backward visits decoder first, then encoder, then frontend: the LAST parameter to get its gradient in a
-        # segment is the one used FIRST in forward.
+        """Backward reaches the gradient of the encoder output only after the whole decoder (all 16 steps and
+        the hoisted K/V projections) has been differentiated, and the gradient of the frontend features only
+        after the encoder: tensor hooks on those two activations launch the finished segment's all-reduce while
+        the rest of backward is still running.  (Parameter hooks cannot be used: the kernels accumulate into the
+        flat gradient buffer themselves and autograd never sees those gradients.)"""
+        model = self.flat.model
 
-        def fire(seg):
-            def hook(*_):
-                self.launch(seg)
-            return hook
-        # decoder grads are complete once the encoder's last layer starts receiving gradients: hook on the
-        # encoder's last-used parameter would fire too early per step loop, so the decoder segment is launched
-        # when the encoder's final FFN LayerNorm weight gets its gradient.
-        n_enc = len(model.encoder.layer_stack)
-        trig_dec = names["encoder.layer_stack.%d.pos_ffn.layer_norm.weight" % (n_enc - 1)]
-        self._hooks.append(trig_dec.register_post_accumulate_grad_hook(fire("decoder.")))
-        trig_enc = names["visual_frontend.resnet18.layer4.1.bn2.weight"]
-        self._hooks.append(trig_enc.register_post_accumulate_grad_hook(fire("encoder.")))
+        def on_encoder_out(mod, inp, out):
+            t = out[0] if isinstance(out, (tuple, list)) else out
+            if t.requires_grad:
+                t.register_hook(lambda g: self.launch("decoder."))
+
+        def on_frontend_out(mod, inp, out):
+            if out.requires_grad:
+                out.register_hook(lambda g: self.launch("encoder."))
+
+        self._hooks.append(model.encoder.register_forward_hook(on_encoder_out))
+        self._hooks.append(model.visual_frontend.register_forward_hook(on_frontend_out))
 
     def launch(self, seg):
         if self.world <= 1:

@@ -71,9 +71,91 @@ def dropout_state(device):
     return st
 
 
-def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, relu=0, mask=None, ldm=0, accumulate=0):
+_side_streams = {}
+
+
+def side_stream(device):
+    """The per-device second HIP stream used to overlap the two decoder directions."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+_main_streams = {}
+
+
+def set_main_stream(stream):
+    """Remember which stream the side stream forks from / joins to (per device)."""
+    _main_streams[stream.device_index] = stream
+
+
+def _xs_in(*ts):
+    """A tape node running on the side stream reads tensors that the main stream allocated (incoming grads):
+    tell the caching allocator, or the block could be handed to a main-stream kernel while we still read it.
+    Forward needs none of this (fork/join fences on both sides of every layer); backward's engine-inserted
+    syncs are one-directional."""
+    cur = torch.cuda.current_stream()
+    if _side_streams.get(cur.device_index) is not None and cur == _side_streams[cur.device_index]:
+        for t in ts:
+            if t is not None:
+                t.record_stream(cur)
+
+
+def _xs_out(*ts):
+    """...and what it hands back (allocated on the side stream) is consumed on the main stream."""
+    cur = torch.cuda.current_stream()
+    if _side_streams.get(cur.device_index) is not None and cur == _side_streams[cur.device_index]:
+        main = _main_streams.get(cur.device_index)
+        if main is not None:
+            for t in ts:
+                if t is not None:
+                    t.record_stream(main)
+
+
+def join_side_streams():
+    """Make the current stream wait for everything enqueued on the side stream(s) (end of a captured step)."""
+    cur = torch.cuda.current_stream()
+    for idx, st in _side_streams.items():
+        if idx == cur.device_index:
+            cur.wait_stream(st)
+
+
+# split-K workspace: int[4096] tile counters (kept zero by the kernel) + fp32 partial slabs, one per stream so
+# that GEMMs running concurrently on different streams never share slabs
+WS_BYTES = 16 << 20
+_workspaces = {}
+
+
+def _workspace():
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = torch.zeros(WS_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", st.device_index))
+    return ws
+
+
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, relu=0, mask=None, ldm=0, accumulate=0, colsum=None):
+    ws = _workspace()
     call("sbl_gemm_f32", ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), relu, _p(mask), ldm,
-         accumulate, _s())
+         accumulate, _p(colsum), ws.data_ptr(), WS_BYTES, _s())
+
+
+def _gbuf(p):
+    """The persistent gradient buffer of a parameter, if the model was flattened (dp.FlatModel): backward then
+    accumulates into it inside the kernels (GEMM epilogue '+=', atomics) and returns None to autograd, instead of
+    allocating a gradient and having AccumulateGrad add it with a separate kernel (16x per decoder parameter)."""
+    return None if p is None else getattr(p, "_sbl_grad", None)
+
+
+def _target(buf, shape, dev, zero=False):
+    """(tensor to write, accumulate flag, value to hand back to autograd)"""
+    if buf is not None:
+        return buf, 1, None
+    t = (torch.zeros if zero else torch.empty)(shape, device=dev, dtype=torch.float32)
+    return t, 0, t
 
 
 # --------------------------------------------------------------------------- #
@@ -93,6 +175,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
         ctx.relu = relu
+        ctx.gb = (_gbuf(w), _gbuf(b))
         return y
 
     @staticmethod
@@ -103,17 +186,21 @@ class LinearFn(torch.autograd.Function):
             dy = dy * (y > 0).to(dy.dtype)
         M, ldx = _rows(x)
         N, K = w.shape
-        dx = dw = db = None
+        dev = dy.device
+        dx = dw_ret = db_ret = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            dx = torch.empty(M, K, device=dev, dtype=torch.float32)
             gemm(0, 0, M, K, N, dy, N, w, K, dx, K)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-            gemm(1, 0, N, K, M, dy, N, x, ldx, dw, K)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(N, device=dy.device, dtype=torch.float32)
-            call("sbl_colsum_f32", _p(dy), N, _p(db), M, N, 0, _s())
-        return dx, dw, db, None
+            dw, acc, dw_ret = _target(ctx.gb[0], (N, K), dev)
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db, _, db_ret = _target(ctx.gb[1], (N,), dev, zero=True)
+            gemm(1, 0, N, K, M, dy, N, x, ldx, dw, K, accumulate=acc, colsum=db)
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db, acc, db_ret = _target(ctx.gb[1], (N,), dev)
+            call("sbl_colsum_f32", _p(dy), N, _p(db), M, N, acc, _s())
+        return dx, dw_ret, db_ret, None
 
 
 def linear(x, w, b=None, relu=False):
@@ -181,9 +268,11 @@ class AddLayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-        call("sbl_add_layernorm_fwd", _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _s())
+        call("sbl_add_layernorm_fwd", _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, 0.0, None,
+             0, _s())
         ctx.save_for_backward(x2, r2, gamma, mean, rstd)
         ctx.shape = x.shape
+        ctx.gb = (_gbuf(gamma), _gbuf(beta))
         return y.view(x.shape)
 
     @staticmethod
@@ -193,12 +282,12 @@ class AddLayerNormFn(torch.autograd.Function):
         M = x2.size(0)
         dy2 = dy.contiguous().view(-1, D)
         dz = torch.empty_like(dy2)
-        dg = torch.zeros(D, device=dy.device, dtype=torch.float32)
-        db = torch.zeros(D, device=dy.device, dtype=torch.float32)
-        call("sbl_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dg), _p(db),
-             M, D, _s())
+        dg, _, dg_ret = _target(ctx.gb[0], (D,), dy.device, zero=True)
+        db, _, db_ret = _target(ctx.gb[1], (D,), dy.device, zero=True)
+        call("sbl_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dz), None, _p(dg), _p(db),
+             M, D, 0.0, None, 0, _s())
         dz = dz.view(ctx.shape)
-        return dz, (dz if r2 is not None else None), dg, db, None
+        return dz, (dz if r2 is not None else None), dg_ret, db_ret, None
 
 
 class RowScaleFn(torch.autograd.Function):
@@ -311,6 +400,8 @@ class KVProjectFn(torch.autograd.Function):
         kv = torch.empty(M, N2, device=x2.device, dtype=torch.float32)
         gemm(0, 1, M, N2, K, x2, ldx, wk, K, kv, N2, bias=bk)
         ctx.save_for_backward(x2, wk, wv)
+        gw, gb = (_gbuf(wk), _gbuf(wv)), (_gbuf(bk), _gbuf(bv))
+        ctx.gb = (gw[0], gb[0]) if all(g is not None for g in gw + gb) and _adjacent(*gw) and _adjacent(*gb) else (None, None)
         return kv
 
     @staticmethod
@@ -319,14 +410,16 @@ class KVProjectFn(torch.autograd.Function):
         dkv = dkv.contiguous()
         M, ldx = _rows(x2)
         N2, K = 2 * wk.size(0), wk.size(1)
-        dx = torch.empty(M, K, device=dkv.device, dtype=torch.float32)
+        dev = dkv.device
+        dx = torch.empty(M, K, device=dev, dtype=torch.float32)
         gemm(0, 0, M, K, N2, dkv, N2, wk, K, dx, K)
-        dw = torch.empty(N2, K, device=dkv.device, dtype=torch.float32)
-        gemm(1, 0, N2, K, M, dkv, N2, x2, ldx, dw, K)
-        db = torch.empty(N2, device=dkv.device, dtype=torch.float32)
-        call("sbl_colsum_f32", _p(dkv), N2, _p(db), M, N2, 0, _s())
+        dw, acc, dw_ret = _target(ctx.gb[0], (N2, K), dev)
+        db, _, db_ret = _target(ctx.gb[1], (N2,), dev, zero=True)
+        gemm(1, 0, N2, K, M, dkv, N2, x2, ldx, dw, K, accumulate=acc, colsum=db)
         h = N2 // 2
-        return dx, dw[:h], db[:h], dw[h:], db[h:]
+        if dw_ret is None:
+            return dx, None, None, None, None
+        return dx, dw_ret[:h], db_ret[:h], dw_ret[h:], db_ret[h:]
 
 
 class MHAFn(torch.autograd.Function):
@@ -335,6 +428,7 @@ class MHAFn(torch.autograd.Function):
 
     self_attn=True : q, k, v all come from x through ONE fused (M x 3*H*64) GEMM.
     self_attn=False: q from x, [K|V] given pre-projected (kv, shape (B*Lk, 2*H*64)).
+    The output dropout is fused into the LayerNorm kernels, the bias gradients into the weight-gradient GEMMs.
     """
 
     @staticmethod
@@ -353,12 +447,18 @@ class MHAFn(torch.autograd.Function):
             qp, kp, vp = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
             ldq = ldk = ldv = 3 * HD
             Lk = Lq
+            gw, gb = (_gbuf(wq), _gbuf(wk), _gbuf(wv)), (_gbuf(bq), _gbuf(bk), _gbuf(bv))
+            fused_ok = all(g is not None for g in gw + gb) and _adjacent(*gw) and _adjacent(*gb)
+            g_qkv = (gw[0], gb[0]) if fused_ok else (None, None)
         else:
             qkv = torch.empty(M, HD, device=dev, dtype=torch.float32)
             gemm(0, 1, M, HD, D, x2, D, wq, D, qkv, HD, bias=bq)
             Lk = kv.size(0) // B
             qp, kp, vp = qkv, kv, kv[:, HD:]
             ldq, ldk, ldv = HD, 2 * HD, 2 * HD
+            g_qkv = (_gbuf(wq), _gbuf(bq))
+            if g_qkv[0] is None or g_qkv[1] is None:
+                g_qkv = (None, None)
         att = torch.empty(M, HD, device=dev, dtype=torch.float32)
         p = torch.empty(H * B, Lq, Lk, device=dev, dtype=torch.float32)
         seed, off_a, off_o = None, 0, 0
@@ -369,14 +469,14 @@ class MHAFn(torch.autograd.Function):
              Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
         o = torch.empty(M, D, device=dev, dtype=torch.float32)
         gemm(0, 1, M, D, HD, att, HD, wfc, HD, o, D, bias=bfc)
-        if drop_p > 0:
-            call("sbl_dropout", _p(o), _p(o), M * D, drop_p, _p(seed), off_o, _s())
         y = torch.empty(M, D, device=dev, dtype=torch.float32)
         mean = torch.empty(M, device=dev, dtype=torch.float32)
         rstd = torch.empty(M, device=dev, dtype=torch.float32)
-        call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _s())
+        call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, drop_p,
+             _p(seed), off_o, _s())
         ctx.save_for_backward(x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed)
         ctx.cfg = (B, Lq, Lk, D, H, drop_p, off_a, off_o, self_attn)
+        ctx.gb = (g_qkv, (_gbuf(wfc), _gbuf(bfc)), (_gbuf(gamma), _gbuf(beta)))
         ctx.mark_non_differentiable(p)
         return y.view(B, Lq, D), p
 
@@ -384,57 +484,58 @@ class MHAFn(torch.autograd.Function):
     def backward(ctx, dy, _dp):
         x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed = ctx.saved_tensors
         B, Lq, Lk, D, H, drop_p, off_a, off_o, self_attn = ctx.cfg
+        g_qkv, g_fc, g_ln = ctx.gb
         M, HD, dev = B * Lq, H * 64, dy.device
+        _xs_in(dy)
         dy2 = dy.contiguous().view(M, D)
-        # LayerNorm(o + x) adjoint -> dz (gradient of both o and the residual x)
+        # LayerNorm(dropout(o) + x) adjoint: dz = grad of the residual x, do = grad of the pre-dropout o
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
-        dgamma = torch.zeros(D, device=dev, dtype=torch.float32)
-        dbeta = torch.zeros(D, device=dev, dtype=torch.float32)
-        call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
-             _p(dbeta), M, D, _s())
-        do = dz
-        if drop_p > 0:
-            do = torch.empty_like(dz)
-            call("sbl_dropout", _p(dz), _p(do), M * D, drop_p, _p(seed), off_o, _s())
-        # fc
-        dwfc = torch.empty(D, HD, device=dev, dtype=torch.float32)
-        gemm(1, 0, D, HD, M, do, D, att, HD, dwfc, HD)
-        dbfc = torch.empty(D, device=dev, dtype=torch.float32)
-        call("sbl_colsum_f32", _p(do), D, _p(dbfc), M, D, 0, _s())
+        do = torch.empty(M, D, device=dev, dtype=torch.float32) if drop_p > 0 else None
+        dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
+        dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
+        call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(do), _p(dgamma),
+             _p(dbeta), M, D, drop_p, _p(seed), off_o, _s())
+        if do is None:
+            do = dz
+        # fc: dW (+ bias grad riding on it), then input gradient
+        dwfc, acc, dwfc_ret = _target(g_fc[0], (D, HD), dev)
+        dbfc, _, dbfc_ret = _target(g_fc[1], (D,), dev, zero=True)
+        gemm(1, 0, D, HD, M, do, D, att, HD, dwfc, HD, accumulate=acc, colsum=dbfc)
         datt = torch.empty(M, HD, device=dev, dtype=torch.float32)
         gemm(0, 0, M, HD, D, do, D, wfc, HD, datt, HD)
-        # attention core
+        dx = dz          # residual-branch gradient; the projection's input gradient accumulates on top of it
         if self_attn:
             dqkv = torch.empty(M, 3 * HD, device=dev, dtype=torch.float32)
-            qp, kp, vp = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
             ld = 3 * HD
-            call("sbl_attention_bwd", _p(datt), HD, _p(qp), ld, _p(kp), ld, _p(vp), ld, _p(p), _p(dqkv), ld,
-                 _p(dqkv[:, HD:]), ld, _p(dqkv[:, 2 * HD:]), ld, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
-            dw = torch.empty(3 * HD, D, device=dev, dtype=torch.float32)
-            gemm(1, 0, 3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D)
-            db = torch.empty(3 * HD, device=dev, dtype=torch.float32)
-            call("sbl_colsum_f32", _p(dqkv), 3 * HD, _p(db), M, 3 * HD, 0, _s())
-            dx = dz          # residual branch gradient; the projection's input gradient accumulates on top
+            call("sbl_attention_bwd", _p(datt), HD, _p(qkv), ld, _p(qkv[:, HD:]), ld, _p(qkv[:, 2 * HD:]), ld, _p(p),
+                 _p(dqkv), ld, _p(dqkv[:, HD:]), ld, _p(dqkv[:, 2 * HD:]), ld, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed),
+                 off_a, _s())
+            dw, acc, dw_ret = _target(g_qkv[0], (3 * HD, D), dev)
+            db, _, db_ret = _target(g_qkv[1], (3 * HD,), dev, zero=True)
+            gemm(1, 0, 3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D, accumulate=acc, colsum=db)
             gemm(0, 0, M, D, 3 * HD, dqkv, 3 * HD, wq, D, dx, D, accumulate=1)
-            return (dx.view(B, Lq, D), None, dw[:HD], db[:HD], dw[HD:2 * HD], db[HD:2 * HD], dw[2 * HD:], db[2 * HD:],
-                    dwfc, dbfc, dgamma, dbeta, None, None, None, None, None)
+            if dw_ret is None:
+                wret = (None,) * 6
+            else:
+                wret = (dw_ret[:HD], db_ret[:HD], dw_ret[HD:2 * HD], db_ret[HD:2 * HD], dw_ret[2 * HD:], db_ret[2 * HD:])
+            _xs_out(dx)
+            return (dx.view(B, Lq, D), None) + wret + (dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret, None, None, None, None, None)
         dq = torch.empty(M, HD, device=dev, dtype=torch.float32)
         dkv = torch.empty(B * Lk, 2 * HD, device=dev, dtype=torch.float32)
         call("sbl_attention_bwd", _p(datt), HD, _p(qkv), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(p), _p(dq), HD,
              _p(dkv), 2 * HD, _p(dkv[:, HD:]), 2 * HD, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
-        dwq = torch.empty(HD, D, device=dev, dtype=torch.float32)
-        gemm(1, 0, HD, D, M, dq, HD, x2, D, dwq, D)
-        dbq = torch.empty(HD, device=dev, dtype=torch.float32)
-        call("sbl_colsum_f32", _p(dq), HD, _p(dbq), M, HD, 0, _s())
-        dx = dz
+        dwq, acc, dwq_ret = _target(g_qkv[0], (HD, D), dev)
+        dbq, _, dbq_ret = _target(g_qkv[1], (HD,), dev, zero=True)
+        gemm(1, 0, HD, D, M, dq, HD, x2, D, dwq, D, accumulate=acc, colsum=dbq)
         gemm(0, 0, M, D, HD, dq, HD, wq, D, dx, D, accumulate=1)
-        return (dx.view(B, Lq, D), dkv, dwq, dbq, None, None, None, None, dwfc, dbfc, dgamma, dbeta,
+        _xs_out(dx, dkv)
+        return (dx.view(B, Lq, D), dkv, dwq_ret, dbq_ret, None, None, None, None, dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret,
                 None, None, None, None, None)
 
 
 class FFNFn(torch.autograd.Function):
     """PositionwiseFeedForward.forward (module.py:47-52) as one tape node:
-    LayerNorm(dropout(relu(x W1^T + b1) W2^T + b2) + x)."""
+    LayerNorm(dropout(relu(x W1^T + b1) W2^T + b2) + x); dropout fused into the LayerNorm kernels."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, gamma, beta, drop_p, eps):
@@ -451,44 +552,45 @@ class FFNFn(torch.autograd.Function):
         if drop_p > 0:
             st = dropout_state(dev)
             seed, off = st.seed, st.next_offset()
-            call("sbl_dropout", _p(o), _p(o), M * D, drop_p, _p(seed), off, _s())
         y = torch.empty(M, D, device=dev, dtype=torch.float32)
         mean = torch.empty(M, device=dev, dtype=torch.float32)
         rstd = torch.empty(M, device=dev, dtype=torch.float32)
-        call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _s())
+        call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, drop_p,
+             _p(seed), off, _s())
         ctx.save_for_backward(x2, h, o, mean, rstd, w1, w2, gamma, seed)
         ctx.cfg = (shp, drop_p, off)
+        ctx.gb = ((_gbuf(w1), _gbuf(b1)), (_gbuf(w2), _gbuf(b2)), (_gbuf(gamma), _gbuf(beta)))
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, h, o, mean, rstd, w1, w2, gamma, seed = ctx.saved_tensors
         shp, drop_p, off = ctx.cfg
+        g1, g2, g_ln = ctx.gb
         M, D = x2.shape
         F_, dev = w1.size(0), dy.device
+        _xs_in(dy)
         dy2 = dy.contiguous().view(M, D)
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
-        dgamma = torch.zeros(D, device=dev, dtype=torch.float32)
-        dbeta = torch.zeros(D, device=dev, dtype=torch.float32)
-        call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dgamma),
-             _p(dbeta), M, D, _s())
-        do = dz
-        if drop_p > 0:
-            do = torch.empty_like(dz)
-            call("sbl_dropout", _p(dz), _p(do), M * D, drop_p, _p(seed), off, _s())
-        dw2 = torch.empty(D, F_, device=dev, dtype=torch.float32)
-        gemm(1, 0, D, F_, M, do, D, h, F_, dw2, F_)
-        db2 = torch.empty(D, device=dev, dtype=torch.float32)
-        call("sbl_colsum_f32", _p(do), D, _p(db2), M, D, 0, _s())
+        do = torch.empty(M, D, device=dev, dtype=torch.float32) if drop_p > 0 else None
+        dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
+        dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
+        call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(do), _p(dgamma),
+             _p(dbeta), M, D, drop_p, _p(seed), off, _s())
+        if do is None:
+            do = dz
+        dw2, acc, dw2_ret = _target(g2[0], (D, F_), dev)
+        db2, _, db2_ret = _target(g2[1], (D,), dev, zero=True)
+        gemm(1, 0, D, F_, M, do, D, h, F_, dw2, F_, accumulate=acc, colsum=db2)
         dh = torch.empty(M, F_, device=dev, dtype=torch.float32)
         gemm(0, 0, M, F_, D, do, D, w2, F_, dh, F_, mask=h, ldm=F_)      # ReLU adjoint fused in the epilogue
-        dw1 = torch.empty(F_, D, device=dev, dtype=torch.float32)
-        gemm(1, 0, F_, D, M, dh, F_, x2, D, dw1, D)
-        db1 = torch.empty(F_, device=dev, dtype=torch.float32)
-        call("sbl_colsum_f32", _p(dh), F_, _p(db1), M, F_, 0, _s())
+        dw1, acc, dw1_ret = _target(g1[0], (F_, D), dev)
+        db1, _, db1_ret = _target(g1[1], (F_,), dev, zero=True)
+        gemm(1, 0, F_, D, M, dh, F_, x2, D, dw1, D, accumulate=acc, colsum=db1)
         dx = dz
         gemm(0, 0, M, D, F_, dh, F_, w1, D, dx, D, accumulate=1)
-        return dx.view(shp), dw1, db1, dw2, db2, dgamma, dbeta, None, None
+        _xs_out(dx)
+        return dx.view(shp), dw1_ret, db1_ret, dw2_ret, db2_ret, dgamma_ret, dbeta_ret, None, None
 
 
 # --------------------------------------------------------------------------- #
@@ -506,15 +608,16 @@ class EmbedPEFn(torch.autograd.Function):
         call("sbl_embed_pe_fwd", _p(tok), tok.stride(0), _p(emb), _p(pe), _p(out), B, L, D, V, _s())
         # tokens are written in place by later steps, but positions < L never change again
         ctx.tok, ctx.L, ctx.shape = tok, L, (V, D)
+        ctx.gb = _gbuf(emb)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         V, D = ctx.shape
         dy = dy.contiguous()
-        demb = torch.zeros(V, D, device=dy.device, dtype=torch.float32)
+        demb, _, demb_ret = _target(ctx.gb, (V, D), dy.device, zero=True)
         call("sbl_embed_bwd", _p(ctx.tok), ctx.tok.stride(0), _p(dy), _p(demb), dy.size(0), ctx.L, D, V, _s())
-        return None, None, demb, None
+        return None, None, demb_ret, None
 
 
 class FusionFn(torch.autograd.Function):

@@ -67,6 +67,7 @@ class Decoder(nn.Module):
         self.tgt_word_prj_l2r = nn.Linear(512, 58, bias=False)
         self.tgt_word_prj_r2l = nn.Linear(512, 58, bias=False)
 
+        self.two_streams = True    # run the two directions' layers on two HIP streams (joined before each fusion)
         self.coins_dev = None      # optional device int32[16]: 1 = feed own argmax (graph replay)
         self.last_coins = None     # the coins of the last forward (host list), for inspection / parity tests
 
@@ -113,13 +114,28 @@ class Decoder(nn.Module):
         golds = (gold_l2r, gold_r2l)
         outs = ([], [])
         coins = []
+        side = main = None
+        if self.two_streams and dev.type == "cuda":
+            main = torch.cuda.current_stream(dev)
+            side = ops.side_stream(dev)
+            ops.set_main_stream(main)
         for i in range(maxlen):
             L = i + 1
             x = [ops.dropout(ops.EmbedPEFn.apply(ys[d], L, emb, pe), self.dropout.p, self.training) for d in (0, 1)]
             for n in range(self.n_layers):
                 slf_mask = 'causal' if n == 0 else None       # decoder.py:123-125 vs :150,:157
-                for d in (0, 1):
-                    x[d], _, _ = layers[d][n](x[d], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[d][n])
+                if side is None:
+                    for d in (0, 1):
+                        x[d], _, _ = layers[d][n](x[d], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[d][n])
+                else:
+                    # the l2r and r2l layers are independent until the fusion: run them on two HIP streams so their
+                    # small kernels overlap on the 256 CUs (fork / join is captured as parallel hipGraph branches;
+                    # autograd replays backward on the same two streams)
+                    side.wait_stream(main)
+                    x[0], _, _ = layers[0][n](x[0], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[0][n])
+                    with torch.cuda.stream(side):
+                        x[1], _, _ = layers[1][n](x[1], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[1][n])
+                    main.wait_stream(side)
                 x[0], x[1] = ops.FusionFn.apply(x[0], x[1])
             preds = [ops.linear(x[d][:, -1], heads[d]) for d in (0, 1)]
             outs[0].append(preds[0])

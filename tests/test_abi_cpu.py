@@ -47,12 +47,12 @@ def test_invalid_arguments_are_rejected_on_the_host():
     """Shape / pointer validation happens before any launch, so this is safe without a GPU."""
     from sbl_for_multilingual_lip_reading_amd import _lib
     with pytest.raises(_lib.SblHipError, match="non-positive dims"):
-        _lib.call("sbl_gemm_f32", 0, 1, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, None)
+        _lib.call("sbl_gemm_f32", 0, 1, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, None, None, 0, None)
     with pytest.raises(_lib.SblHipError, match="Lq,Lk <= 64"):
         _lib.call("sbl_attention_fwd", None, 64, None, 64, None, 64, None, 64, None, 0, None, 1, 1, 65, 4, 0.125, 0.0,
                   None, 0, None)
     with pytest.raises(_lib.SblHipError, match="D=256"):
-        _lib.call("sbl_add_layernorm_fwd", None, None, None, None, None, None, None, 4, 256, 1e-5, None)
+        _lib.call("sbl_add_layernorm_fwd", None, None, None, None, None, None, None, 4, 256, 1e-5, 0.0, None, 0, None)
 
 
 def test_state_dict_surface_matches_reference():

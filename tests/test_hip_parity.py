@@ -312,7 +312,8 @@ def test_ffn_module_golden(ops, golden_modules):
     for k, p in ff.named_parameters():
         got = p.grad[::8, ::8] if p.dim() == 2 else p.grad
         assert maxdiff(got, g["ffn.grad:" + k]) < 1e-4, k
-    assert maxdiff(PositionalEncoding(512, max_len=64).pe[0], g["pe"]) == 0.0
+    # the table is built on the host with torch.sin/cos (module.py:17-22): libm differs by an ulp or two across CPUs
+    assert maxdiff(PositionalEncoding(512, max_len=64).pe[0], g["pe"]) < 1e-5
 
 
 def test_decoder_layer_and_fusion_golden(ops, golden_modules):
@@ -521,6 +522,46 @@ def test_e2e_matches_oracle_other_seed(ops):
             assert maxdiff(p.grad, r) < 2e-3 * float(r.abs().max()) + 2e-6, n
 
 
+def test_flat_direct_accumulation_and_two_streams_match_plain_autograd(ops):
+    """The throughput path (dp.FlatModel: kernels accumulate gradients straight into one flat buffer, the two
+    decoder directions on two HIP streams, dropout fused into LayerNorm with p=0) must give the same numbers as
+    the plain per-tensor autograd path the golden tests exercise.  Also: two accumulating steps == 2x gradient."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    B, T, H, W, ne, nd = 3, 4, 24, 24, 1, 2
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 33)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+
+    def run(m):
+        random.seed(9)
+        pl, gl, pr, gr = m(xd, ld, rd)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        return pl.detach().clone(), loss.item()
+
+    m1 = build_model(ne, nd).train()
+    m1.decoder.two_streams = False
+    pl1, loss1 = run(m1)
+    g1 = {n: p.grad.clone() for n, p in m1.named_parameters()}
+    m2 = build_model(ne, nd).train()
+    flat = dp.FlatModel(m2)
+    assert m2.decoder.two_streams
+    flat.zero_grad()
+    pl2, loss2 = run(m2)
+    torch.cuda.synchronize()
+    assert maxdiff(pl2, pl1) < 2e-5 and abs(loss1 - loss2) < 1e-5
+    for n, p in m2.named_parameters():
+        ref = g1[n]
+        tol = 2e-2 if n.startswith("visual_frontend") else 1e-3     # BN-amplified fp32 reorder noise, see above
+        assert maxdiff(p.grad, ref) < tol * float(ref.abs().max()) + 2e-6, n
+    first = flat.flat_grad.clone()
+    # running stats moved after step 1, so step 2's frontend grads differ slightly; the transformer part doubles
+    run(m2)
+    torch.cuda.synchronize()
+    a, b = flat.ranges["decoder."]
+    assert relerr(flat.flat_grad[a:b], 2 * first[a:b]) < 1e-3
+
+
 @pytest.mark.parametrize("tag", ["small", "full"])
 def test_recognize_golden(ops, tag):
     g = load_golden("recognize_%s.npz" % tag)
@@ -598,9 +639,11 @@ def test_full_size_properties(ops):
     # linearity of the conv in its input: stats of conv(2x) = 2*mean, 4*var  => running stats follow
     rm2, rv2 = bn.running_mean.clone(), bn.running_var.clone()
     pooled2 = ops.StemFn.apply(2 * x, conv.weight, bn.weight, bn.bias, rm2, rv2, True, 0.1, 1e-5)
-    assert maxdiff(pooled2, pooled) < 1e-4            # train-mode BN is scale invariant
+    # train-mode BN is scale invariant up to eps: var ~ 0.03 here, so eps/var ~ 3e-4 relative
+    assert maxdiff(pooled2, pooled) < 3e-3
     d_mean, d_mean2 = rm - 0.9 * bn.running_mean, rm2 - 0.9 * bn.running_mean
-    assert relerr(d_mean2, 2 * d_mean) < 1e-4
+    # the means are ~2e-5 (sum of 15 M near-cancelling terms, double atomics in arbitrary order): absolute check
+    assert maxdiff(d_mean2, 2 * d_mean) < 1e-7 + 1e-3 * float(d_mean.abs().max())
     feats = fe(x)
     assert feats.shape == (32, 29, 512) and bool(torch.isfinite(feats).all())
     # per-sample independence is broken only by BN statistics: permuting the batch permutes the outputs
