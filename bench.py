@@ -13,8 +13,11 @@ HBM.  The step is captured once into a hipGraph (after the warm-up) and replayed
 replay because their seed / flags live in device memory.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — the dominant kernel of the step (by rocprofv3 time share, profiles/): HIP-event-timed live,
-                 on the launch stream, over the timed region's own launches
+  roofline     — the dominant kernel family of the step by GPU time.  Every GEMM / convolution launch of the step
+                 is timed live, inside replays of the same captured step, by in-kernel s_memrealtime stamps
+                 (min start / max end over the launch's workgroups; include/sbl_hip.h sbl_profile_*), i.e. on the
+                 stream the kernel runs on and with the real inter-kernel concurrency.  achieved = algorithmic
+                 FLOPs of the family's launches / their summed durations.  `families` lists the others.
   cpu_baseline — the CPU oracle (oracle/sbl_oracle.py, the fixture-pinned restatement of the reference) timed on the
                  host cores of this box on a bounded sample, N=1 / rank 0 only
 """
@@ -33,10 +36,14 @@ sys.path.insert(0, ROOT)
 
 T_FRAMES, HW = 29, 88
 PER_GPU_BATCH = 32
-# algorithmic work of the trunk's layer1 3x3 convolution (the single largest kernel):
-# M = B*T*22*22 output pixels, N = 64, K = 576
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-HBM_PEAK_GBS = 8000.0
+KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW, M<=512)",
+                2: "sbl_mfma_gemm_kernel 64x64 dense (nn.Linear, M>512)",
+                3: "sbl_mfma_gemm_kernel 128x128 dense",
+                4: "sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (trunk conv fwd + BN stats)",
+                5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
+                6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)"}
+T_START = time.perf_counter()
 
 
 def parse():
@@ -49,6 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="run eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented replays behind `roofline`")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--single-stream", action="store_true", help="run the two decoder directions on one stream")
     ap.add_argument("--hang-dump", type=int, default=0, help="debug: dump all Python stacks after this many seconds")
@@ -59,9 +67,6 @@ def parse():
 def log(args, msg):
     if args.verbose:
         print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
-
-
-T_START = time.perf_counter()
 
 
 def build_model(device, dropout_on):
@@ -84,37 +89,36 @@ def build_model(device, dropout_on):
     return m.to(device).train()
 
 
-class KernelTimer:
-    """HIP events around one named C-ABI entry point, on the stream it is launched on (torch's current stream),
-    collected inside the timed region."""
+class LaunchRecorder:
+    """While active, notes (slot, kernel id, algorithmic FLOPs) of every instrumented GEMM / conv launch."""
 
-    def __init__(self, name, shape_filter=None):
-        self.name, self.filter, self.events, self.enabled = name, shape_filter, [], False
-
-    def install(self):
-        from sbl_for_multilingual_lip_reading_amd import ops
+    def __init__(self):
+        from sbl_for_multilingual_lip_reading_amd import _lib, ops
+        self.ops, self.lib, self.active, self.launches = ops, _lib.load(), False, []
         inner = ops.call
 
-        def call(name, *args):
-            if self.enabled and name == self.name and (self.filter is None or self.filter(args)):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                inner(name, *args)
-                b.record()
-                self.events.append((a, b))
+        def call(name, *a):
+            inner(name, *a)
+            if not self.active:
+                return
+            if name == "sbl_gemm_f32":
+                fl = 2.0 * a[2] * a[3] * a[4]
+            elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_wgrad"):
+                off = 1 if name == "sbl_conv2d_fwd" else 0
+                nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
+                ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+                fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
             else:
-                inner(name, *args)
+                return
+            slot = self.lib.sbl_profile_last_slot()
+            if slot >= 0:
+                self.launches.append((slot, self.lib.sbl_profile_last_kernel(), fl))
         ops.call = call
-
-    def mean_ms(self):
-        if not self.events:
-            return None
-        return float(np.mean([a.elapsed_time(b) for a, b in self.events]))
 
 
 def cpu_baseline(batch):
-    """CPU oracle fwd + loss + bwd on `batch` clips of the same synthetic workload (dropout neutralised: the
-    oracle's dropout switch costs nothing relative to the convolutions)."""
+    """CPU oracle fwd + loss + bwd on `batch` clips of the same synthetic workload (dropout neutralised: its cost
+    is nothing next to the convolutions)."""
     from oracle import sbl_oracle as O
     from sbl_for_multilingual_lip_reading_amd import detfill
     # the box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole host and
@@ -167,7 +171,8 @@ def main():
 
     from sbl_for_multilingual_lip_reading_amd import _lib, detfill, dp, ops
     from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
-    _lib.load()          # fail loudly if the HIP library is missing
+    lib = _lib.load()          # fail loudly if the HIP library is missing
+    rec = LaunchRecorder()
 
     B = args.batch
     model = build_model(dev, not args.no_dropout)
@@ -186,9 +191,6 @@ def main():
     drop = ops.dropout_state(dev)
     loss_out = torch.zeros((), device=dev)
 
-    timer = KernelTimer("sbl_conv2d_fwd", lambda a: a[7] == 64 and a[8] == 64 and a[9] == 3)   # layer1 3x3 convs
-    timer.install()
-
     def fwd_bwd():
         drop.begin_step()
         flat.zero_grad()
@@ -203,47 +205,43 @@ def main():
         loss_out.copy_(loss.detach())
 
     def new_coins():
-        coins_dev.copy_(torch.tensor([int(rng.random() > 0.5) for _ in range(16)], dtype=torch.int32), non_blocking=False)
+        coins_dev.copy_(torch.tensor([int(rng.random() > 0.5) for _ in range(16)], dtype=torch.int32))
 
-    # eager warm-up (also first-touch of every kernel / attribute before capture)
-    graph = None
-    for w in range(max(args.warmup, 1)):
-        new_coins()
-        fwd_bwd()
-        exchange.finish()
+    # eager warm-up on the stream the graph will be captured on (its split-K workspaces get created here)
+    cap_stream = torch.cuda.Stream()
+    cap_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap_stream):
+        for _ in range(max(args.warmup, 1)):
+            new_coins()
+            fwd_bwd()
+            exchange.finish()
     torch.cuda.synchronize()
     log(args, "eager warm-up done")
+
+    graph = None
     if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fwd_bwd()                    # one more eager run on the capture stream
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        log(args, "capture begin")
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):     # same stream as the warm-up: its split-K workspace exists
+        with torch.cuda.graph(graph, stream=cap_stream):
             fwd_bwd()
         log(args, "capture + instantiate done")
         torch.cuda.synchronize()
-        new_coins()
-        graph.replay()
-        exchange.finish()
-        torch.cuda.synchronize()
-        log(args, "first replay done")
 
     def step():
         new_coins()
         if graph is not None:
             graph.replay()
+            exchange.finish()
         else:
-            fwd_bwd()
-        exchange.finish()
+            with torch.cuda.stream(cap_stream):
+                fwd_bwd()
+                exchange.finish()
 
+    step()
+    torch.cuda.synchronize()
+    log(args, "first timed-style step done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = graph is None       # events cannot be recorded inside a replay; see below
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -251,39 +249,59 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    timer.enabled = False
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     loss_val = float(loss_out.item())
+    log(args, "timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
 
-    # dominant kernel, timed live with HIP events on its launch stream.  When the step is replayed from a graph
-    # the events cannot sit inside the replay, so the same kernel is re-launched on the same operands right after
-    # the timed region (same process, same clocks), 20 launches, events around each.
-    kernel_ms = timer.mean_ms()
-    if kernel_ms is None and rank == 0:
-        NT = B * T_FRAMES
-        xa = torch.randn(NT, 22, 22, 64, device=dev)
-        w = torch.randn(64, 3, 3, 64, device=dev)
-        y = torch.empty(NT, 22, 22, 64, device=dev)
-        st = torch.empty(128, device=dev, dtype=torch.float64)
-        evs = []
-        for i in range(25):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            ops._lib.call("sbl_conv2d_fwd", xa.data_ptr(), w.data_ptr(), y.data_ptr(), st.data_ptr(), NT, 22, 22, 64, 64, 3, 3, 1, 1,
-                          torch.cuda.current_stream().cuda_stream)
-            b.record()
-            if i >= 5:
-                evs.append((a, b))
-        torch.cuda.synchronize()
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # ---- per-kernel GPU time inside replays of the same step (in-kernel stamps, see docstring)
+    fam = {}
+    if rank == 0 and not args.no_kernel_timing:
+        CAP = 32768
+        init = torch.zeros(CAP, 2, dtype=torch.int64, device=dev)
+        init[:, 0] = -1                                   # as uint64: +inf for atomicMin
+        stamps = init.clone()
+        lib.sbl_profile_begin(stamps.data_ptr(), CAP)
+        rec.active = True
+        if graph is not None:
+            pgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(pgraph, stream=cap_stream):
+                fwd_bwd()
+            run = pgraph.replay
+        else:
+            def run():
+                with torch.cuda.stream(cap_stream):
+                    fwd_bwd()
+            run()
+        rec.active = False
+        used = lib.sbl_profile_end()
+        launches = rec.launches[:used] if graph is not None else rec.launches
+        reps = 3
+        dur = np.zeros(CAP)
+        for _ in range(reps):
+            stamps.copy_(init)
+            torch.cuda.synchronize()
+            if graph is not None:
+                run()
+            else:
+                lib.sbl_profile_begin(stamps.data_ptr(), CAP)
+                run()
+                lib.sbl_profile_end()
+            torch.cuda.synchronize()
+            s = stamps.cpu().numpy()
+            dur += (s[:, 1] - s[:, 0]) / 100.0            # 100 MHz ticks -> microseconds
+        dur /= reps
+        for slot, kid, fl in launches:
+            f = fam.setdefault(kid, {"launches": 0, "us": 0.0, "flops": 0.0})
+            f["launches"] += 1
+            f["us"] += float(dur[slot])
+            f["flops"] += fl
+        log(args, "kernel timing done (%d instrumented launches per step)" % len(launches))
 
     if rank == 0:
         clips = B * world * args.steps
-        flops = 2.0 * (B * T_FRAMES * 22 * 22) * 64 * 576          # algorithmic FLOPs of one layer1 conv launch
-        achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None
         out = {
             "metric": "lip-clips/sec fwd+bwd (29x88x88)", "value": round(clips / dt, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -291,13 +309,24 @@ def main():
             "config": {"workload": ("full SBL 6+6 (Conv3d stem + ResNet-18 + encoder + SBL decoder) fwd+loss+bwd"
                                     if args.workload == "full" else "visual frontend only (Conv3d stem + ResNet-18) fwd+bwd"),
                        "per_gpu_batch": B, "global_batch": B * world, "clip": "29x88x88", "parallelism": "dp%d" % world,
-                       "dropout": not args.no_dropout, "bn": "train", "hipgraph": graph is not None, "loss": round(loss_val, 5)},
-            "roofline": {"bound": "mfma", "kernel": "sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (trunk layer1 conv3x3 fwd, "
-                                                    "M=%d N=64 K=576)" % (B * T_FRAMES * 484),
-                         "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel_ms": None if kernel_ms is None else round(kernel_ms, 4)},
+                       "dropout": not args.no_dropout, "bn": "train", "hipgraph": graph is not None,
+                       "decoder_streams": 1 if args.single_stream else 2, "loss": round(loss_val, 5)},
         }
+        if fam:
+            fams = []
+            for kid, f in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
+                tf = f["flops"] / (f["us"] * 1e-6) / 1e12
+                fams.append({"kernel": KERNEL_NAMES.get(kid, str(kid)), "launches_per_step": f["launches"],
+                             "ms_per_step": round(f["us"] / 1e3, 3), "avg_launch_us": round(f["us"] / f["launches"], 2),
+                             "achieved_TFLOPs": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
+            top = fams[0]
+            out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_TFLOPs"],
+                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_of_fp32_mfma_peak"],
+                               "traffic": None, "avg_launch_us": top["avg_launch_us"],
+                               "launches_per_step": top["launches_per_step"], "ms_per_step": top["ms_per_step"],
+                               "families": fams[1:]}
+        else:
+            out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)

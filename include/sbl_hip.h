@@ -35,6 +35,16 @@ typedef void* sbl_stream_t; /* hipStream_t */
 const char* sbl_last_error(void);
 int sbl_abi_version(void);
 
+/* Bench instrumentation (debug; process-wide): between begin/end every GEMM / convolution launch gets a slot
+ * stamps[2*slot] = min start, stamps[2*slot+1] = max end of its workgroups, in 100 MHz s_memrealtime ticks
+ * (caller pre-fills starts with ~0 and ends with 0).  The slot pointer is baked into the launch, so stamps are
+ * taken inside hipGraph replays too.  sbl_profile_last_slot/kernel report the launch just enqueued by this thread
+ * (slot -1 = not instrumented; kernel 1 skinny GEMM, 2 tiled 64x64, 3 tiled 128x128, 4/5/6 conv fwd/dgrad/wgrad). */
+int sbl_profile_begin(uint64_t* stamps, int capacity);
+int sbl_profile_end(void);
+int sbl_profile_last_slot(void);
+int sbl_profile_last_kernel(void);
+
 /* ---------------------------------------------------------------- dense GEMM / Linear
  * C[M,N] (+)= opA(A)[M,K] * opB(B)[K,N], row-major; opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k],
  * opB(B)[k,n] = transB ? B[n*ldb+k] : B[k*ldb+n].  Epilogue: +bias[n], ReLU, or multiply by

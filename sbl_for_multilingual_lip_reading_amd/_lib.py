@@ -68,6 +68,11 @@ def load():
     lib.sbl_last_error.argtypes = []
     lib.sbl_abi_version.restype = c_int
     lib.sbl_abi_version.argtypes = []
+    for name in ("sbl_profile_end", "sbl_profile_last_slot", "sbl_profile_last_kernel"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = []
+    lib.sbl_profile_begin.restype = c_int
+    lib.sbl_profile_begin.argtypes = [c_void_p, c_int]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
         fn.restype = c_int

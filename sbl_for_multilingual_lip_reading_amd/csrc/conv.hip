@@ -25,16 +25,17 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad};
     if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+    SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};
 #define SBL_CONV_FWD(BM, BN)                                                                                   \
     do {                                                                                                       \
         ConvGatherKC<BM, false> al{x, g, M};                                                                   \
         DenseKC<BN, true> bl{w, (long)K, N};                                                                   \
         if (stats) {                                                                                           \
             EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0};                                    \
-            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN>(al, bl, e, M, N, K, 1, s); \
+            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
         } else {                                                                                               \
             EpiStore<0, false> e{y, (long)N, nullptr, 0, nullptr, nullptr, 0};                                 \
-            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s); \
+            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
         }                                                                                                      \
     } while (0)
     if (N >= 128 && t128 >= 512) SBL_CONV_FWD(128, 128);
@@ -54,12 +55,13 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
     const int M = NIMG * H * W, N = Cin, K = KH * KW * Cout;
     ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad};
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+    SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
 #define SBL_CONV_DG(BM, BN)                                                                                   \
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
         DenseKC<BN, true> bl{wt, (long)K, N};                                                                 \
         EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
-        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s); \
+        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
     } while (0)
     if (N >= 128 && t128 >= 512) SBL_CONV_DG(128, 128);
     else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_DG(128, 64);
@@ -86,7 +88,8 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     DenseMC<64, true> al{dy, (long)Cout, M};
     ConvGatherMC<64> bl{x, g, N};
     EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};
-    sbl_launch_gemm<DenseMC<64, true>, ConvGatherMC<64>, EpiStore<2, false>, 64, 64>(al, bl, e, M, N, K, splits, s);
+    SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_WGRAD)};
+    sbl_launch_gemm<DenseMC<64, true>, ConvGatherMC<64>, EpiStore<2, false>, 64, 64>(al, bl, e, M, N, K, splits, s, sc);
     SBL_LAUNCH_CHECK("sbl_conv2d_wgrad");
     return 0;
 }

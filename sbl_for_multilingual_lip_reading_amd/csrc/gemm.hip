@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "mfma_gemm.h"
+#include "skinny_gemm.h"
 
 // ------------------------------------------------------------------ error text (thread-local)
 static thread_local char g_err[512] = "";
@@ -12,6 +13,33 @@ void sbl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* sbl_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ bench instrumentation (process-wide, debug only)
+static unsigned long long* g_stamps = nullptr;
+static int g_stamp_cap = 0, g_stamp_used = 0;
+static thread_local int g_last_slot = -1, g_last_kid = 0;
+unsigned long long* sbl_next_stamp_slot(int kernel_id) {
+    g_last_kid = kernel_id;
+    g_last_slot = -1;
+    if (!g_stamps || g_stamp_used >= g_stamp_cap) return nullptr;
+    g_last_slot = g_stamp_used++;
+    return g_stamps + 2 * (size_t)g_last_slot;
+}
+extern "C" int sbl_profile_begin(uint64_t* stamps_dev, int capacity) {
+    SBL_REQUIRE(stamps_dev && capacity > 0, "sbl_profile_begin: bad args");
+    g_stamps = (unsigned long long*)stamps_dev;
+    g_stamp_cap = capacity;
+    g_stamp_used = 0;
+    return 0;
+}
+extern "C" int sbl_profile_end(void) {
+    const int used = g_stamp_used;
+    g_stamps = nullptr;
+    g_stamp_cap = g_stamp_used = 0;
+    return used;
+}
+extern "C" int sbl_profile_last_slot(void) { return g_last_slot; }
+extern "C" int sbl_profile_last_kernel(void) { return g_last_kid; }
 extern "C" int sbl_abi_version(void) { return SBL_ABI_VERSION; }
 
 // ------------------------------------------------------------------ dispatch
@@ -82,7 +110,7 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
         if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
     }
-    SplitCtl sc{nullptr, nullptr, a_colsum};
+    SplitCtl sc{nullptr, nullptr, a_colsum, nullptr};
     int mode = accumulate ? 1 : 0;
     if (splits > 1) {
         const long need = (long)sizeof(int) * SBL_WS_COUNTERS + tiles64 * splits * (long)(64 * 64 * sizeof(float));
@@ -96,6 +124,23 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
             splits = 1;
         }
     }
+    // decoder-sized products: register-only skinny kernel (one workgroup per 32x32 tile, K split over its waves)
+    {
+        const bool a_kc = !transA, b_kc = transB != 0;
+        const bool al_ok = (!a_kc || (sbl_aligned16(A) && lda % 4 == 0)) && (!b_kc || (sbl_aligned16(B) && ldb % 4 == 0));
+        const bool k_ok = (!a_kc && !b_kc) || (K % 8 == 0);
+        const long tiles32 = (long)sbl_cdiv(M, 32) * sbl_cdiv(N, 32);
+        const bool shape_ok = transA ? (K <= 512 && tiles32 <= 2048) : (M <= 512 && tiles32 <= 2048);
+        if (shape_ok && al_ok && k_ok && !(transA && transB)) {
+            SkinnyEpi e{C, ldc, bias, relu, relu_mask, ldm, accumulate, a_colsum, sbl_next_stamp_slot(SBL_KID_SKINNY)};
+            if (!transA && transB) sbl_launch_skinny<true, true>(A, lda, B, ldb, e, M, N, K, s);
+            else if (!transA && !transB) sbl_launch_skinny<true, false>(A, lda, B, ldb, e, M, N, K, s);
+            else sbl_launch_skinny<false, false>(A, lda, B, ldb, e, M, N, K, s);
+            SBL_LAUNCH_CHECK("sbl_gemm_f32(skinny)");
+            return 0;
+        }
+    }
+    sc.stamp = sbl_next_stamp_slot(big ? SBL_KID_TILED128 : SBL_KID_TILED64);
 #define SBL_GO(VEC, BM, BN, KU) \
     launch_trans<VEC, BM, BN, KU>(transA, transB, A, lda, B, ldb, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s)
     if (big) {

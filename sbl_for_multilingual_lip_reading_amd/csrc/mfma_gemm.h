@@ -325,6 +325,7 @@ struct SplitCtl {
     float* slabs;
     int* counters;
     float* a_colsum;
+    unsigned long long* stamp;   // bench instrumentation slot or nullptr
 };
 
 // KU = BK-deep sub-tiles staged per barrier ("macro step" = KU*16 of K).  KU = 1 for the big, occupancy-rich
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
+    sbl_stamp_begin(sc.stamp);
 
     typename AL::State sa;
     typename BL::State sb;
@@ -447,7 +449,10 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
             s_last = last;
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last) {
+            sbl_stamp_end(sc.stamp);
+            return;
+        }
         const float* base = sc.slabs + (long)tile * nz * (BM * BN) + tid;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -482,11 +487,12 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
             }
         }
     }
+    sbl_stamp_end(sc.stamp);
 }
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1>
 static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int splits,
-                                   hipStream_t s, SplitCtl sc = SplitCtl{nullptr, nullptr, nullptr}) {
+                                   hipStream_t s, SplitCtl sc = SplitCtl{nullptr, nullptr, nullptr, nullptr}) {
     constexpr int MK = KU * SBL_BK;
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);

@@ -267,53 +267,67 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
     const float4 g0 = *reinterpret_cast<const float4*>(gamma + lane * 4), g1 = *reinterpret_cast<const float4*>(gamma + 256 + lane * 4);
     const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
     float dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // each wave owns RW consecutive rows per trip and issues all of their loads before the first reduction, so
+    // the (dependent) shuffle reductions of one row overlap the memory latency of the next
+    constexpr int RW = 4;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const long o = (long)row * 512;
-        float v[8], d[8];
-        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + o + lane * 4);
-        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(x + o + 256 + lane * 4);
-        bool keep[8];
+    for (int rb = r0 + wave * RW; rb < r1; rb += 4 * RW) {
+        float v[RW][8], d[RW][8], mu[RW], rs[RW];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            keep[k] = true;
-            if (thresh) {
-                keep[k] = sbl_keep(sd, offset, (uint64_t)o + (k < 4 ? 0 : 256) + lane * 4 + (k & 3), thresh);
-                v[k] = keep[k] ? v[k] * keep_scale : 0.f;
+        for (int j = 0; j < RW; ++j) {
+            const int row = min(rb + j, r1 - 1);
+            const long o = (long)row * 512;
+            *reinterpret_cast<float4*>(v[j]) = *reinterpret_cast<const float4*>(x + o + lane * 4);
+            *reinterpret_cast<float4*>(v[j] + 4) = *reinterpret_cast<const float4*>(x + o + 256 + lane * 4);
+            *reinterpret_cast<float4*>(d[j]) = *reinterpret_cast<const float4*>(dy + o + lane * 4);
+            *reinterpret_cast<float4*>(d[j] + 4) = *reinterpret_cast<const float4*>(dy + o + 256 + lane * 4);
+            mu[j] = mean[row];
+            rs[j] = rstd[row];
+        }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int row = rb + j;
+            if (row >= r1) break;
+            const long o = (long)row * 512;
+            bool keep[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                keep[k] = true;
+                if (thresh) {
+                    keep[k] = sbl_keep(sd, offset, (uint64_t)o + (k < 4 ? 0 : 256) + lane * 4 + (k & 3), thresh);
+                    v[j][k] = keep[k] ? v[j][k] * keep_scale : 0.f;
+                }
             }
-        }
-        if (res) {
-            const float4 q0 = *reinterpret_cast<const float4*>(res + o + lane * 4);
-            const float4 q1 = *reinterpret_cast<const float4*>(res + o + 256 + lane * 4);
-            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
-            v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
-        }
-        *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dy + o + lane * 4);
-        *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(dy + o + 256 + lane * 4);
-        const float mu = mean[row], rs = rstd[row];
-        float s1 = 0.f, s2 = 0.f, xh[8];
+            if (res) {
+                const float4 q0 = *reinterpret_cast<const float4*>(res + o + lane * 4);
+                const float4 q1 = *reinterpret_cast<const float4*>(res + o + 256 + lane * 4);
+                v[j][0] += q0.x; v[j][1] += q0.y; v[j][2] += q0.z; v[j][3] += q0.w;
+                v[j][4] += q1.x; v[j][5] += q1.y; v[j][6] += q1.z; v[j][7] += q1.w;
+            }
+            float s1 = 0.f, s2 = 0.f, xh[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            xh[k] = (v[k] - mu) * rs;
-            const float gd = ga[k] * d[k];
-            s1 += gd;
-            s2 += gd * xh[k];
-            dg[k] += d[k] * xh[k];
-            db[k] += d[k];
-        }
-        s1 = wave_sum(s1) * (1.f / 512.f);
-        s2 = wave_sum(s2) * (1.f / 512.f);
-        float out[8];
+            for (int k = 0; k < 8; ++k) {
+                xh[k] = (v[j][k] - mu[j]) * rs[j];
+                const float gd = ga[k] * d[j][k];
+                s1 += gd;
+                s2 += gd * xh[k];
+                dg[k] += d[j][k] * xh[k];
+                db[k] += d[j][k];
+            }
+            s1 = wave_sum(s1) * (1.f / 512.f);
+            s2 = wave_sum(s2) * (1.f / 512.f);
+            float out[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = rs * (ga[k] * d[k] - s1 - xh[k] * s2);
-        *reinterpret_cast<float4*>(dz + o + lane * 4) = *reinterpret_cast<float4*>(out);
-        *reinterpret_cast<float4*>(dz + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
-        if (dx_drop) {   // gradient w.r.t. the pre-dropout x
+            for (int k = 0; k < 8; ++k) out[k] = rs[j] * (ga[k] * d[j][k] - s1 - xh[k] * s2);
+            *reinterpret_cast<float4*>(dz + o + lane * 4) = *reinterpret_cast<float4*>(out);
+            *reinterpret_cast<float4*>(dz + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
+            if (dx_drop) {   // gradient w.r.t. the pre-dropout x
 #pragma unroll
-            for (int k = 0; k < 8; ++k) out[k] = keep[k] ? out[k] * keep_scale : 0.f;
-            *reinterpret_cast<float4*>(dx_drop + o + lane * 4) = *reinterpret_cast<float4*>(out);
-            *reinterpret_cast<float4*>(dx_drop + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
+                for (int k = 0; k < 8; ++k) out[k] = keep[k] ? out[k] * keep_scale : 0.f;
+                *reinterpret_cast<float4*>(dx_drop + o + lane * 4) = *reinterpret_cast<float4*>(out);
+                *reinterpret_cast<float4*>(dx_drop + o + 256 + lane * 4) = *reinterpret_cast<float4*>(out + 4);
+            }
         }
     }
 #pragma unroll
@@ -353,9 +367,10 @@ extern "C" int sbl_add_layernorm_bwd(const float* dy, const float* x, const floa
     SBL_REQUIRE(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && M > 0, "sbl_add_layernorm_bwd: bad args");
     SBL_REQUIRE(sbl_aligned16(dy) && sbl_aligned16(x) && sbl_aligned16(dz) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma), "sbl_add_layernorm_bwd: unaligned");
     // few, fat workgroups: each ends with 1024 float atomics on the same dgamma/dbeta words
-    int blocks = sbl_cdiv(M, 32);
-    if (blocks > 64) blocks = 64;
-    const int rpb = sbl_cdiv(M, blocks);
+    // 16 rows per workgroup (4 waves x 4 rows in flight); each workgroup ends with 1024 float atomics
+    int blocks = sbl_cdiv(M, 16);
+    if (blocks > 128) blocks = 128;
+    const int rpb = sbl_cdiv(sbl_cdiv(M, blocks), 16) * 16;
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(sbl_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, x, res,
                        gamma, mean, rstd, dz, dx_drop, dgamma, dbeta, M, rpb, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
                        1.f / (1.f - drop_p), seed, offset);

@@ -37,6 +37,23 @@ void sbl_set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// ---- optional in-kernel wall-clock stamps (bench instrumentation; off unless sbl_profile_begin() was called)
+// slot[0] = min over workgroups of the start time, slot[1] = max of the end time, 100 MHz s_memrealtime ticks.
+// Works inside hipGraph replays (the slot pointer is baked into the captured launch).
+unsigned long long* sbl_next_stamp_slot(int kernel_id);   // host side; nullptr when profiling is off
+__device__ __forceinline__ void sbl_stamp_begin(unsigned long long* slot) {
+    if (slot && threadIdx.x == 0) atomicMin(slot, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void sbl_stamp_end(unsigned long long* slot) {
+    if (slot && threadIdx.x == 0) atomicMax(slot + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+#define SBL_KID_SKINNY 1
+#define SBL_KID_TILED64 2
+#define SBL_KID_TILED128 3
+#define SBL_KID_CONV_FWD 4
+#define SBL_KID_CONV_DGRAD 5
+#define SBL_KID_CONV_WGRAD 6
+
 static inline int sbl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool sbl_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -9,6 +9,8 @@ non-zero status raises.
 All Functions are hipGraph-capturable: no host sync, no host read of device data;
 dropout seeds and teacher-forcing coins live in device memory.
 """
+import os
+
 import torch
 
 try:
@@ -114,12 +116,52 @@ def _xs_out(*ts):
                     t.record_stream(main)
 
 
-def join_side_streams():
-    """Make the current stream wait for everything enqueued on the side stream(s) (end of a captured step)."""
+_aux_streams = {}
+# Off by default: with the decoder's second stream also forking an auxiliary stream, hipStreamEndCapture /
+# instantiate segfaults on ROCm 7.2 (main+aux and main+side capture fine; main+side+aux does not), and
+# main+side (92.8 ms/step) beats main+aux (113 ms).  SBL_OFFLOAD_WGRAD=1 enables it for single-stream runs.
+OFFLOAD_WGRAD = os.environ.get("SBL_OFFLOAD_WGRAD", "0") == "1"
+
+
+def _aux_for(cur):
+    """Auxiliary stream paired with `cur`: weight-gradient GEMMs are not on backward's dependency chain (nothing
+    downstream reads dW before the step ends), so they are issued there and overlap the chain of small
+    dX / attention / LayerNorm kernels instead of lengthening it."""
+    key = (cur.device_index, cur.cuda_stream)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(device=cur.device_index)
+    return st
+
+
+def wgrad_gemm(M, N, K, A, lda, B, ldb, C, ldc, acc, colsum):
+    """dW (+)= A^T B with the bias gradient riding on it.  When the destination is a persistent gradient buffer
+    (acc=1) the launch goes to the auxiliary stream; the operands are pinned for that stream."""
+    if not (acc and OFFLOAD_WGRAD):
+        gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, accumulate=acc, colsum=colsum)
+        return
     cur = torch.cuda.current_stream()
-    for idx, st in _side_streams.items():
-        if idx == cur.device_index:
-            cur.wait_stream(st)
+    aux = _aux_for(cur)
+    aux.wait_stream(cur)
+    with torch.cuda.stream(aux):
+        gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, accumulate=1, colsum=colsum)
+    A.record_stream(aux)
+    B.record_stream(aux)
+
+
+def join_side_streams():
+    """Make the current stream wait for everything enqueued on the side / auxiliary streams (end of a step).
+    Each auxiliary stream is joined only into the stream it was forked from."""
+    cur = torch.cuda.current_stream()
+    side = _side_streams.get(cur.device_index)
+    if side is not None:
+        a = _aux_streams.get((cur.device_index, side.cuda_stream))
+        if a is not None:
+            side.wait_stream(a)
+        cur.wait_stream(side)
+    a = _aux_streams.get((cur.device_index, cur.cuda_stream))
+    if a is not None:
+        cur.wait_stream(a)
 
 
 # split-K workspace: int[4096] tile counters (kept zero by the kernel) + fp32 partial slabs, one per stream so
@@ -415,7 +457,7 @@ class KVProjectFn(torch.autograd.Function):
         gemm(0, 0, M, K, N2, dkv, N2, wk, K, dx, K)
         dw, acc, dw_ret = _target(ctx.gb[0], (N2, K), dev)
         db, _, db_ret = _target(ctx.gb[1], (N2,), dev, zero=True)
-        gemm(1, 0, N2, K, M, dkv, N2, x2, ldx, dw, K, accumulate=acc, colsum=db)
+        wgrad_gemm(N2, K, M, dkv, N2, x2, ldx, dw, K, acc, db)
         h = N2 // 2
         if dw_ret is None:
             return dx, None, None, None, None
@@ -490,7 +532,10 @@ class MHAFn(torch.autograd.Function):
         dy2 = dy.contiguous().view(M, D)
         # LayerNorm(dropout(o) + x) adjoint: dz = grad of the residual x, do = grad of the pre-dropout o
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
-        do = torch.empty(M, D, device=dev, dtype=torch.float32) if drop_p > 0 else None
+        # a separate pre-dropout gradient buffer is also needed without dropout when the weight-gradient GEMM reads
+        # it from the auxiliary stream while this stream accumulates the input gradient into dz in place
+        sep = drop_p > 0 or (OFFLOAD_WGRAD and g_fc[0] is not None)
+        do = torch.empty(M, D, device=dev, dtype=torch.float32) if sep else None
         dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
         dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
         call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(do), _p(dgamma),
@@ -500,7 +545,7 @@ class MHAFn(torch.autograd.Function):
         # fc: dW (+ bias grad riding on it), then input gradient
         dwfc, acc, dwfc_ret = _target(g_fc[0], (D, HD), dev)
         dbfc, _, dbfc_ret = _target(g_fc[1], (D,), dev, zero=True)
-        gemm(1, 0, D, HD, M, do, D, att, HD, dwfc, HD, accumulate=acc, colsum=dbfc)
+        wgrad_gemm(D, HD, M, do, D, att, HD, dwfc, HD, acc, dbfc)
         datt = torch.empty(M, HD, device=dev, dtype=torch.float32)
         gemm(0, 0, M, HD, D, do, D, wfc, HD, datt, HD)
         dx = dz          # residual-branch gradient; the projection's input gradient accumulates on top of it
@@ -512,7 +557,7 @@ class MHAFn(torch.autograd.Function):
                  off_a, _s())
             dw, acc, dw_ret = _target(g_qkv[0], (3 * HD, D), dev)
             db, _, db_ret = _target(g_qkv[1], (3 * HD,), dev, zero=True)
-            gemm(1, 0, 3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D, accumulate=acc, colsum=db)
+            wgrad_gemm(3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D, acc, db)
             gemm(0, 0, M, D, 3 * HD, dqkv, 3 * HD, wq, D, dx, D, accumulate=1)
             if dw_ret is None:
                 wret = (None,) * 6
@@ -526,7 +571,7 @@ class MHAFn(torch.autograd.Function):
              _p(dkv), 2 * HD, _p(dkv[:, HD:]), 2 * HD, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
         dwq, acc, dwq_ret = _target(g_qkv[0], (HD, D), dev)
         dbq, _, dbq_ret = _target(g_qkv[1], (HD,), dev, zero=True)
-        gemm(1, 0, HD, D, M, dq, HD, x2, D, dwq, D, accumulate=acc, colsum=dbq)
+        wgrad_gemm(HD, D, M, dq, HD, x2, D, dwq, D, acc, dbq)
         gemm(0, 0, M, D, HD, dq, HD, wq, D, dx, D, accumulate=1)
         _xs_out(dx, dkv)
         return (dx.view(B, Lq, D), dkv, dwq_ret, dbq_ret, None, None, None, None, dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret,
@@ -572,7 +617,10 @@ class FFNFn(torch.autograd.Function):
         _xs_in(dy)
         dy2 = dy.contiguous().view(M, D)
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
-        do = torch.empty(M, D, device=dev, dtype=torch.float32) if drop_p > 0 else None
+        # a separate pre-dropout gradient buffer is also needed without dropout when the weight-gradient GEMM reads
+        # it from the auxiliary stream while this stream accumulates the input gradient into dz in place
+        sep = drop_p > 0 or (OFFLOAD_WGRAD and g2[0] is not None)
+        do = torch.empty(M, D, device=dev, dtype=torch.float32) if sep else None
         dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
         dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
         call("sbl_add_layernorm_bwd", _p(dy2), _p(o), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(do), _p(dgamma),
@@ -581,12 +629,12 @@ class FFNFn(torch.autograd.Function):
             do = dz
         dw2, acc, dw2_ret = _target(g2[0], (D, F_), dev)
         db2, _, db2_ret = _target(g2[1], (D,), dev, zero=True)
-        gemm(1, 0, D, F_, M, do, D, h, F_, dw2, F_, accumulate=acc, colsum=db2)
+        wgrad_gemm(D, F_, M, do, D, h, F_, dw2, F_, acc, db2)
         dh = torch.empty(M, F_, device=dev, dtype=torch.float32)
         gemm(0, 0, M, F_, D, do, D, w2, F_, dh, F_, mask=h, ldm=F_)      # ReLU adjoint fused in the epilogue
         dw1, acc, dw1_ret = _target(g1[0], (F_, D), dev)
         db1, _, db1_ret = _target(g1[1], (F_,), dev, zero=True)
-        gemm(1, 0, F_, D, M, dh, F_, x2, D, dw1, D, accumulate=acc, colsum=db1)
+        wgrad_gemm(F_, D, M, dh, F_, x2, D, dw1, D, acc, db1)
         dx = dz
         gemm(0, 0, M, D, F_, dh, F_, w1, D, dx, D, accumulate=1)
         _xs_out(dx)

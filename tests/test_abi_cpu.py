@@ -30,7 +30,11 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if n not in exported]
     assert not missing, missing
     # ctypes table == header (minus the two non-int helpers)
-    assert sorted(_lib.SIGNATURES) == sorted(n for n in names if n not in ("sbl_last_error", "sbl_abi_version"))
+    helpers = ("sbl_last_error", "sbl_abi_version", "sbl_profile_begin", "sbl_profile_end", "sbl_profile_last_slot",
+               "sbl_profile_last_kernel")      # bound by hand in _lib.load()
+    assert sorted(_lib.SIGNATURES) == sorted(n for n in names if n not in helpers)
+    for h in helpers:
+        assert hasattr(lib, h)
 
 
 def test_ctypes_arity_matches_header():
