@@ -9,8 +9,10 @@ A "step" = one optimizer-free training step of the reference (SBL/train.py:188-1
 batch of 32 clips per GPU (Conv3d stem -> ResNet-18 -> 6-layer encoder -> 16-step SBL decoder), the two
 label-smoothed losses, loss.backward(), and for N > 1 the gradient average over ranks.  Dropout is ON (it is part
 of the reference step), BatchNorm in training mode, fp32 throughout.  Inputs are synthetic and already resident in
-HBM.  The step is captured once into a hipGraph (after the warm-up) and replayed; masks and coins still change per
-replay because their seed / flags live in device memory.
+HBM.  The step is captured into hipGraphs after the warm-up and replayed: dropout masks change per replay (their
+seed lives in device memory); the 16 teacher-forcing coins (decoder.py:176) determine which decoder steps can be
+batched, hence the launch sequence, so --coin-patterns random patterns are drawn (seed 7, same on every rank), one
+graph is captured per pattern and the timed loop cycles through them.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — the dominant kernel family of the step by GPU time.  Every GEMM / convolution launch of the step
@@ -57,7 +59,9 @@ def parse():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented replays behind `roofline`")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="clips in the one CPU-oracle step (32 ~ 7 s on 16 cores)")
+    ap.add_argument("--coin-patterns", type=int, default=4, help="distinct teacher-forcing coin patterns (one graph each)")
+    ap.add_argument("--per-step-decoder", action="store_true", help="one decoder stage per step (no run batching)")
     ap.add_argument("--single-stream", action="store_true", help="run the two decoder directions on one stream")
     ap.add_argument("--hang-dump", type=int, default=0, help="debug: dump all Python stacks after this many seconds")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
@@ -184,10 +188,12 @@ def main():
     x_np, l2r_np, r2l_np = detfill.synthetic_batch(B, T_FRAMES, HW, HW, 7 + rank)
     x = torch.from_numpy(x_np).to(dev)
     l2r, r2l = torch.from_numpy(l2r_np).to(dev), torch.from_numpy(r2l_np).to(dev)
-    coins_dev = torch.zeros(16, dtype=torch.int32, device=dev)
-    model.decoder.coins_dev = coins_dev
+    # teacher-forcing coins (decoder.py:176): the decoder batches the steps of each teacher-forced run, so the
+    # launch sequence depends on the coin pattern.  A few patterns are drawn (same seed on every rank),
+    # one hipGraph is captured per pattern and the timed loop cycles through them.
+    patterns = [[rng_c.random() > 0.5 for _ in range(16)] for rng_c in [random.Random(7)] for _ in range(args.coin_patterns)]
     model.decoder.two_streams = not args.single_stream
-    rng = random.Random(7)            # same coin sequence on every rank
+    model.decoder.batch_teacher_runs = not args.per_step_decoder
     drop = ops.dropout_state(dev)
     loss_out = torch.zeros((), device=dev)
 
@@ -204,34 +210,42 @@ def main():
         ops.join_side_streams()          # the decoder's second stream rejoins before the step ends
         loss_out.copy_(loss.detach())
 
-    def new_coins():
-        coins_dev.copy_(torch.tensor([int(rng.random() > 0.5) for _ in range(16)], dtype=torch.int32))
+    def set_coins(i):
+        model.decoder.coins_host = patterns[i % len(patterns)]
 
     # eager warm-up on the stream the graph will be captured on (its split-K workspaces get created here)
     cap_stream = torch.cuda.Stream()
     cap_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(cap_stream):
-        for _ in range(max(args.warmup, 1)):
-            new_coins()
+        for w in range(max(args.warmup, 1)):
+            set_coins(w)
             fwd_bwd()
             exchange.finish()
     torch.cuda.synchronize()
     log(args, "eager warm-up done")
 
     graph = None
+    graphs = []
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=cap_stream):
-            fwd_bwd()
-        log(args, "capture + instantiate done")
+        for i in range(len(patterns)):
+            set_coins(i)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap_stream):
+                fwd_bwd()
+            graphs.append(g)
+        graph = graphs[0]
+        log(args, "capture + instantiate done (%d coin patterns)" % len(graphs))
         torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        new_coins()
+        i = step_no[0]
+        step_no[0] += 1
         if graph is not None:
-            graph.replay()
+            graphs[i % len(graphs)].replay()
             exchange.finish()
         else:
+            set_coins(i)
             with torch.cuda.stream(cap_stream):
                 fwd_bwd()
                 exchange.finish()
@@ -265,6 +279,7 @@ def main():
         stamps = init.clone()
         lib.sbl_profile_begin(stamps.data_ptr(), CAP)
         rec.active = True
+        set_coins(0)
         if graph is not None:
             pgraph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(pgraph, stream=cap_stream):
@@ -310,7 +325,10 @@ def main():
                                     if args.workload == "full" else "visual frontend only (Conv3d stem + ResNet-18) fwd+bwd"),
                        "per_gpu_batch": B, "global_batch": B * world, "clip": "29x88x88", "parallelism": "dp%d" % world,
                        "dropout": not args.no_dropout, "bn": "train", "hipgraph": graph is not None,
-                       "decoder_streams": 1 if args.single_stream else 2, "loss": round(loss_val, 5)},
+                       "decoder_streams": 1 if args.single_stream else 2,
+                       "decoder_schedule": "per-step" if args.per_step_decoder else "teacher-forced runs batched",
+                       "coin_patterns": len(patterns), "own_argmax_coins": [sum(p_) for p_ in patterns],
+                       "loss": round(loss_val, 5)},
         }
         if fam:
             fams = []

@@ -62,6 +62,12 @@ int sbl_profile_last_kernel(void);
 int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                  float* C, long ldc, const float* bias, int relu, const float* relu_mask, long ldm, int accumulate,
                  float* a_colsum, void* ws, long ws_bytes, sbl_stream_t stream);
+/* Deferred weight gradient of one decoder weight over all stages of a step:
+ * C[M,N] += sum_s A_s^T B_s with A_s (seg_rows[s] x M, row stride lda) = dY of stage s and B_s (seg_rows[s] x N) = its
+ * input; a_colsum[m] += column sums of the A_s (bias gradient).  A_ptrs / B_ptrs / seg_rows are HOST arrays of nseg
+ * <= 16 entries (device pointers inside).  C and a_colsum are accumulated with float atomics (split-K). */
+int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda, const float* const* B_ptrs, long ldb,
+                      const int* seg_rows, int M, int N, float* C, long ldc, float* a_colsum, sbl_stream_t stream);
 /* out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
 int sbl_colsum_f32(const float* X, long ldx, float* out, int M, int N, int accumulate, sbl_stream_t stream);
 
@@ -161,6 +167,34 @@ int sbl_attention_bwd(const float* dout, long lddo, const float* q, long ldq, co
                       long ldv, const float* p, float* dq, long lddq, float* dk, long lddk, float* dv, long lddv,
                       int B, int H, int Lq, int Lk, float scale, float drop_p, const uint64_t* seed, uint64_t offset,
                       sbl_stream_t stream);
+
+/* Ragged ("segmented") forms.  A run of decoder steps whose input tokens are all known (teacher-forced) has no
+ * step-to-step dependency (decoder.py:176-186 feeds back the argmax only when the coin says so), so the run is
+ * processed as ONE batch: segment s = the step with prefix length seg_L[s]; its B*seg_L[s] rows follow segment
+ * s-1's rows, in (b, l) order.  seg_L is a HOST array of nseg <= 16 lengths.  Lk_fixed == 0: self-attention inside
+ * each segment; Lk_fixed > 0: all segments attend to the same (B, Lk_fixed) key/value rows (cross-attention) and,
+ * in backward with nseg > 1, dk/dv are accumulated with float atomics into caller-zeroed buffers.
+ * p_out holds the segments' (H*B, L, Lk) probability blocks back to back. */
+int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o,
+                          long ldo, float* p_out, int mask_kind, const uint8_t* mask, int B, int H, const int* seg_L,
+                          int nseg, int Lk_fixed, float scale, float drop_p, const uint64_t* seed, uint64_t offset,
+                          sbl_stream_t stream);
+int sbl_attention_seg_bwd(const float* dout, long lddo, const float* q, long ldq, const float* k, long ldk, const float* v,
+                          long ldv, const float* p, float* dq, long lddq, float* dk, long lddk, float* dv, long lddv,
+                          int B, int H, const int* seg_L, int nseg, int Lk_fixed, float scale, float drop_p,
+                          const uint64_t* seed, uint64_t offset, sbl_stream_t stream);
+int sbl_embed_pe_seg_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B,
+                         const int* seg_L, int nseg, int D, int V, sbl_stream_t stream);
+int sbl_embed_seg_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, const int* seg_L, int nseg, int D,
+                      int V, sbl_stream_t stream);
+int sbl_fusion_seg_fwd(const float* a, const float* b, float* a2, float* b2, int B, const int* seg_L, int nseg, int D,
+                       sbl_stream_t stream);
+int sbl_fusion_seg_bwd(const float* da2, const float* db2, float* da, float* db, int B, const int* seg_L, int nseg, int D,
+                       sbl_stream_t stream);
+/* out[s*B + b, :] = x[last row of sequence (s, b)]: the rows the output heads read (decoder.py:166-167);
+ * bwd zero-fills dx (all rows) and scatters the nseg*B gradient rows back */
+int sbl_gather_last_fwd(const float* x, float* out, int B, const int* seg_L, int nseg, int D, sbl_stream_t stream);
+int sbl_gather_last_bwd(const float* dy, float* dx, int B, const int* seg_L, int nseg, int D, sbl_stream_t stream);
 
 /* ---------------------------------------------------------------- SBL decoder pieces
  * out[b,l,:] = emb[tok[b*ldt + l]] + pe[l]: decoder.py:116-120 */

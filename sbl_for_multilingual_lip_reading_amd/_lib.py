@@ -12,6 +12,7 @@ P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 # name -> argtypes (all return int); mirrors include/sbl_hip.h one to one
 SIGNATURES = {
     "sbl_gemm_f32": [I, I, I, I, I, P, L, P, L, P, L, P, I, P, L, I, P, P, L, P],
+    "sbl_wgrad_seg_f32": [I, P, L, P, L, P, I, I, P, L, P, P],
     "sbl_colsum_f32": [P, L, P, I, I, I, P],
     "sbl_stem_conv_fwd": [P, P, P, P, I, I, I, I, P],
     "sbl_stem_bn_relu_pool_fwd": [P, P, P, P, P, P, P, I, I, I, P],
@@ -37,6 +38,14 @@ SIGNATURES = {
     "sbl_rowscale": [P, P, P, L, I, P],
     "sbl_attention_fwd": [P, L, P, L, P, L, P, L, P, I, P, I, I, I, I, F, F, P, U64, P],
     "sbl_attention_bwd": [P, L, P, L, P, L, P, L, P, P, L, P, L, P, L, I, I, I, I, F, F, P, U64, P],
+    "sbl_attention_seg_fwd": [P, L, P, L, P, L, P, L, P, I, P, I, I, P, I, I, F, F, P, U64, P],
+    "sbl_attention_seg_bwd": [P, L, P, L, P, L, P, L, P, P, L, P, L, P, L, I, I, P, I, I, F, F, P, U64, P],
+    "sbl_embed_pe_seg_fwd": [P, L, P, P, P, I, P, I, I, I, P],
+    "sbl_embed_seg_bwd": [P, L, P, P, I, P, I, I, I, P],
+    "sbl_fusion_seg_fwd": [P, P, P, P, I, P, I, I, P],
+    "sbl_fusion_seg_bwd": [P, P, P, P, I, P, I, I, P],
+    "sbl_gather_last_fwd": [P, P, I, P, I, I, P],
+    "sbl_gather_last_bwd": [P, P, I, P, I, I, P],
     "sbl_embed_pe_fwd": [P, L, P, P, P, I, I, I, I, P],
     "sbl_embed_bwd": [P, L, P, P, I, I, I, I, P],
     "sbl_fusion_fwd": [P, P, P, P, I, I, I, P],

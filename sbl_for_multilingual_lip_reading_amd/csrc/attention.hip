@@ -46,16 +46,23 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
                                                             long ldk, const float* __restrict__ v, long ldv,
                                                             float* __restrict__ o, long ldo, float* __restrict__ p_out,
                                                             int mask_kind, const uint8_t* __restrict__ mask, int B, int H,
-                                                            int Lq, int Lk, float scale, uint32_t thresh, float keep_scale,
-                                                            const uint64_t* __restrict__ seed, uint64_t offset) {
+                                                            SegDesc segs, int Lk_fixed, float scale, uint32_t thresh,
+                                                            float keep_scale, const uint64_t* __restrict__ seed,
+                                                            uint64_t offset) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Qs = smem, *Ks = smem + AT_SZ, *Vs = smem + 2 * AT_SZ, *Ss = smem + 3 * AT_SZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // block -> (segment, batch row, head).  Self-attention (Lk_fixed == 0): keys are the segment's own rows;
+    // cross-attention: every segment attends to the same (B, Lk_fixed) key/value rows.
+    const int sidx = blockIdx.x / (B * H);
+    const int b = (blockIdx.x / H) % B, h = blockIdx.x % H;
+    const int Lq = segs.L[sidx], Lk = Lk_fixed > 0 ? Lk_fixed : Lq;
+    const long qrow = segs.row_off[sidx] + (long)b * Lq;
+    const long krow = Lk_fixed > 0 ? (long)b * Lk : qrow;
     const int Lqp = (Lq + 31) & ~31, Lkp = (Lk + 31) & ~31;
-    load_head(Qs, q + (long)b * Lq * ldq + h * 64, ldq, Lq, Lqp, tid);
-    load_head(Ks, k + (long)b * Lk * ldk + h * 64, ldk, Lk, Lkp, tid);
-    load_head(Vs, v + (long)b * Lk * ldv + h * 64, ldv, Lk, Lkp, tid);
+    load_head(Qs, q + qrow * ldq + h * 64, ldq, Lq, Lqp, tid);
+    load_head(Ks, k + krow * ldk + h * 64, ldk, Lk, Lkp, tid);
+    load_head(Vs, v + krow * ldv + h * 64, ldv, Lk, Lkp, tid);
     __syncthreads();
     // S = Q K^T * scale
     const int TQ = Lqp >> 5, TK = Lkp >> 5;
@@ -69,7 +76,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     __syncthreads();
     // softmax over keys, one wavefront per query row
     const uint64_t sd = thresh ? *seed : 0;
-    float* pg = p_out + ((long)h * B + b) * Lq * Lk;
+    const long pbase = segs.p_off[sidx] + ((long)h * B + b) * Lq * Lk;
+    float* pg = p_out + pbase;
     for (int i = wave; i < Lqp; i += 4) {
         float pv = 0.f, pd = 0.f;
         if (i < Lq) {
@@ -82,13 +90,13 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
             if (lane < Lk) pg[(long)i * Lk + lane] = pv;
             pd = pv;
             if (thresh)
-                pd = sbl_keep(sd, offset, ((uint64_t)blockIdx.x * Lq + i) * Lk + lane, thresh) ? pv * keep_scale : 0.f;
+                pd = sbl_keep(sd, offset, (uint64_t)pbase + (uint64_t)i * Lk + lane, thresh) ? pv * keep_scale : 0.f;
         }
         if (lane < Lkp) Ss[i * AT_LD + lane] = pd;
     }
     __syncthreads();
     // O = P V   (contraction over keys; rows >= Lk of P's columns / V are zero)
-    float* og = o + (long)b * Lq * ldo + h * 64;
+    float* og = o + qrow * ldo + h * 64;
     for (int t = wave; t < TQ * 2; t += 4) {
         const int i0 = (t >> 1) * 32, j0 = (t & 1) * 32;
         f32x16 acc = lds_mma(Ss, AT_LD, 1, Vs, AT_LD, 1, i0, j0, Lkp, lane);
@@ -104,41 +112,52 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                                                             long ldq, const float* __restrict__ k, long ldk,
                                                             const float* __restrict__ v, long ldv, const float* __restrict__ p,
                                                             float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
-                                                            float* __restrict__ dv, long lddv, int B, int H, int Lq, int Lk,
-                                                            float scale, uint32_t thresh, float keep_scale,
+                                                            float* __restrict__ dv, long lddv, int B, int H, SegDesc segs,
+                                                            int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
                                                             const uint64_t* __restrict__ seed, uint64_t offset) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Qs = smem, *Ks = smem + AT_SZ, *Vs = smem + 2 * AT_SZ, *Gs = smem + 3 * AT_SZ, *Ps = smem + 4 * AT_SZ,
           *Ds = smem + 5 * AT_SZ;   // Gs = dO, Ps = (dropped) P then dS, Ds = dP
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int sidx = blockIdx.x / (B * H);
+    const int b = (blockIdx.x / H) % B, h = blockIdx.x % H;
+    const int Lq = segs.L[sidx], Lk = Lk_fixed > 0 ? Lk_fixed : Lq;
+    const long qrow = segs.row_off[sidx] + (long)b * Lq;
+    const long krow = Lk_fixed > 0 ? (long)b * Lk : qrow;
     const int Lqp = (Lq + 31) & ~31, Lkp = (Lk + 31) & ~31;
-    load_head(Qs, q + (long)b * Lq * ldq + h * 64, ldq, Lq, Lqp, tid);
-    load_head(Ks, k + (long)b * Lk * ldk + h * 64, ldk, Lk, Lkp, tid);
-    load_head(Vs, v + (long)b * Lk * ldv + h * 64, ldv, Lk, Lkp, tid);
-    load_head(Gs, dout + (long)b * Lq * lddo + h * 64, lddo, Lq, Lqp, tid);
+    load_head(Qs, q + qrow * ldq + h * 64, ldq, Lq, Lqp, tid);
+    load_head(Ks, k + krow * ldk + h * 64, ldk, Lk, Lkp, tid);
+    load_head(Vs, v + krow * ldv + h * 64, ldv, Lk, Lkp, tid);
+    load_head(Gs, dout + qrow * lddo + h * 64, lddo, Lq, Lqp, tid);
     const uint64_t sd = thresh ? *seed : 0;
-    const float* pg = p + ((long)h * B + b) * Lq * Lk;
+    const long pbase = segs.p_off[sidx] + ((long)h * B + b) * Lq * Lk;
+    const float* pg = p + pbase;
     for (int i = tid; i < Lqp * Lkp; i += 256) {   // Ps = P after dropout (zero padded)
         const int r = i / Lkp, c = i - r * Lkp;
         float val = 0.f;
         if (r < Lq && c < Lk) {
             val = pg[(long)r * Lk + c];
-            if (thresh) val = sbl_keep(sd, offset, ((uint64_t)blockIdx.x * Lq + r) * Lk + c, thresh) ? val * keep_scale : 0.f;
+            if (thresh) val = sbl_keep(sd, offset, (uint64_t)pbase + (uint64_t)r * Lk + c, thresh) ? val * keep_scale : 0.f;
         }
         Ps[r * AT_LD + c] = val;
     }
     __syncthreads();
     const int TQ = Lqp >> 5, TK = Lkp >> 5;
     // dV[j][d] = sum_i Pd[i][j] dO[i][d]
-    float* dvg = dv + (long)b * Lk * lddv + h * 64;
+    // cross-attention: several segments (decoder steps of one run) share the key/value rows, so their dK/dV
+    // contributions are accumulated with float atomics into a zero-initialised buffer
+    float* dvg = dv + krow * lddv + h * 64;
+    const bool kv_atomic = Lk_fixed > 0 && segs.nseg > 1;
     for (int t = wave; t < TK * 2; t += 4) {
         const int i0 = (t >> 1) * 32, j0 = (t & 1) * 32;
         f32x16 acc = lds_mma(Ps, 1, AT_LD, Gs, AT_LD, 1, i0, j0, Lqp, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (j < Lk) dvg[(long)j * lddv + j0 + (lane & 31)] = acc[r];
+            if (j < Lk) {
+                if (kv_atomic) atomicAdd(dvg + (long)j * lddv + j0 + (lane & 31), acc[r]);
+                else dvg[(long)j * lddv + j0 + (lane & 31)] = acc[r];
+            }
         }
     }
     // dPd[i][j] = sum_d dO[i][d] V[j][d]
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                 pv = pg[(long)i * Lk + lane];
                 dp = Ds[i * AT_LD + lane];
                 if (thresh)
-                    dp = sbl_keep(sd, offset, ((uint64_t)blockIdx.x * Lq + i) * Lk + lane, thresh) ? dp * keep_scale : 0.f;
+                    dp = sbl_keep(sd, offset, (uint64_t)pbase + (uint64_t)i * Lk + lane, thresh) ? dp * keep_scale : 0.f;
             }
             const float dot = wave_sum(pv * dp);
             ds = pv * (dp - dot) * scale;
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     }
     __syncthreads();
     // dQ[i][d] = sum_j dS[i][j] K[j][d]
-    float* dqg = dq + (long)b * Lq * lddq + h * 64;
+    float* dqg = dq + qrow * lddq + h * 64;
     for (int t = wave; t < TQ * 2; t += 4) {
         const int i0 = (t >> 1) * 32, j0 = (t & 1) * 32;
         f32x16 acc = lds_mma(Ps, AT_LD, 1, Ks, AT_LD, 1, i0, j0, Lkp, lane);
@@ -179,67 +198,101 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
         }
     }
     // dK[j][d] = sum_i dS[i][j] Q[i][d]
-    float* dkg = dk + (long)b * Lk * lddk + h * 64;
+    float* dkg = dk + krow * lddk + h * 64;
     for (int t = wave; t < TK * 2; t += 4) {
         const int i0 = (t >> 1) * 32, j0 = (t & 1) * 32;
         f32x16 acc = lds_mma(Ps, 1, AT_LD, Qs, AT_LD, 1, i0, j0, Lqp, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (j < Lk) dkg[(long)j * lddk + j0 + (lane & 31)] = acc[r];
+            if (j < Lk) {
+                if (kv_atomic) atomicAdd(dkg + (long)j * lddk + j0 + (lane & 31), acc[r]);
+                else dkg[(long)j * lddk + j0 + (lane & 31)] = acc[r];
+            }
         }
     }
 }
 
-static int at_check(const char* who, int B, int H, int Lq, int Lk, long ldq, long ldk, long ldv, long ldo) {
-    SBL_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && Lq <= 64 && Lk <= 64, "%s: need 1 <= Lq,Lk <= 64 (got %d,%d), B=%d H=%d", who, Lq, Lk, B, H);
+static int at_check(const char* who, int B, int H, const SegDesc& d, int Lk_fixed, long ldq, long ldk, long ldv, long ldo) {
+    SBL_REQUIRE(B > 0 && H > 0 && Lk_fixed >= 0 && Lk_fixed <= 64, "%s: bad B=%d H=%d Lk=%d (Lk <= 64)", who, B, H, Lk_fixed);
+    for (int s = 0; s < d.nseg; ++s)
+        SBL_REQUIRE(d.L[s] >= 1 && d.L[s] <= 64, "%s: need 1 <= Lq,Lk <= 64 (segment %d has L=%d)", who, s, d.L[s]);
+    SBL_REQUIRE((long)d.nseg * B * H < (1L << 30), "%s: too many workgroups", who);
     SBL_REQUIRE(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ldo >= H * 64, "%s: row stride smaller than H*64", who);
     SBL_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "%s: row strides must be multiples of 4 floats", who);
     return 0;
 }
 
-extern "C" int sbl_attention_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o,
-                                 long ldo, float* p_out, int mask_kind, const uint8_t* mask, int B, int H, int Lq, int Lk,
-                                 float scale, float drop_p, const uint64_t* seed, uint64_t offset, sbl_stream_t stream) {
-    if (int e = at_check("sbl_attention_fwd", B, H, Lq, Lk, ldq, ldk, ldv, ldo)) return e;
-    SBL_REQUIRE(q && k && v && o && p_out && sbl_aligned16(q) && sbl_aligned16(k) && sbl_aligned16(v), "sbl_attention_fwd: null/unaligned pointer");
-    SBL_REQUIRE(mask_kind >= 0 && mask_kind <= 2 && (mask_kind != 2 || mask), "sbl_attention_fwd: bad mask");
-    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_attention_fwd: bad dropout args");
-    const size_t lds = sizeof(float) * 4 * AT_SZ;   // 66.5 KB > default dynamic-LDS cap: raise it once per device
-    static bool attr_set[64] = {false};
+static int at_attr(const void* fn, size_t lds, bool* flags) {
     int dev = 0;
     SBL_HIP(hipGetDevice(&dev));
-    if (!attr_set[dev & 63]) {
-        SBL_HIP(hipFuncSetAttribute((const void*)attention_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev & 63] = true;
+    if (!flags[dev & 63]) {   // > 64 KB of dynamic LDS: raise the cap once per device
+        SBL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        flags[dev & 63] = true;
     }
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, o,
-                       ldo, p_out, mask_kind, mask, B, H, Lq, Lk, scale, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
+    return 0;
+}
+
+// Segmented form: seg_L = host array of nseg prefix lengths (1..16 entries).  Lk_fixed == 0: self-attention inside
+// each segment (q/k/v rows of segment s start at sum_{t<s} B*seg_L[t]); Lk_fixed > 0: every segment's queries attend
+// to the same (B, Lk_fixed) key/value rows (decoder cross-attention).  p_out holds the segments' probability
+// blocks back to back, each (H*B, L, Lk).  In backward with shared keys and nseg > 1, dk/dv must be zeroed by the
+// caller (contributions are atomically accumulated).
+extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o,
+                                     long ldo, float* p_out, int mask_kind, const uint8_t* mask, int B, int H,
+                                     const int* seg_L, int nseg, int Lk_fixed, float scale, float drop_p,
+                                     const uint64_t* seed, uint64_t offset, sbl_stream_t stream) {
+    SegDesc d;
+    SBL_REQUIRE(sbl_make_segs(d, seg_L, nseg, B, H, Lk_fixed) > 0, "sbl_attention_seg_fwd: bad segment list (nseg=%d, 1..%d)", nseg, SBL_MAX_SEG);
+    if (int e = at_check("sbl_attention_fwd", B, H, d, Lk_fixed, ldq, ldk, ldv, ldo)) return e;
+    SBL_REQUIRE(q && k && v && o && p_out && sbl_aligned16(q) && sbl_aligned16(k) && sbl_aligned16(v), "sbl_attention_fwd: null/unaligned pointer");
+    SBL_REQUIRE(mask_kind >= 0 && mask_kind <= 2 && (mask_kind != 2 || (mask && nseg == 1)), "sbl_attention_fwd: bad mask");
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_attention_fwd: bad dropout args");
+    const size_t lds = sizeof(float) * 4 * AT_SZ;
+    static bool attr_set[64] = {false};
+    if (int e = at_attr((const void*)attention_fwd_kernel, lds, attr_set)) return e;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(nseg * B * H), dim3(256), lds, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, o,
+                       ldo, p_out, mask_kind, mask, B, H, d, Lk_fixed, scale, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
                        1.f / (1.f - drop_p), seed, offset);
     SBL_LAUNCH_CHECK("sbl_attention_fwd");
     return 0;
 }
 
-extern "C" int sbl_attention_bwd(const float* dout, long lddo, const float* q, long ldq, const float* k, long ldk,
-                                 const float* v, long ldv, const float* p, float* dq, long lddq, float* dk, long lddk,
-                                 float* dv, long lddv, int B, int H, int Lq, int Lk, float scale, float drop_p,
-                                 const uint64_t* seed, uint64_t offset, sbl_stream_t stream) {
-    if (int e = at_check("sbl_attention_bwd", B, H, Lq, Lk, ldq, ldk, ldv, lddo)) return e;
+extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* q, long ldq, const float* k, long ldk,
+                                     const float* v, long ldv, const float* p, float* dq, long lddq, float* dk, long lddk,
+                                     float* dv, long lddv, int B, int H, const int* seg_L, int nseg, int Lk_fixed,
+                                     float scale, float drop_p, const uint64_t* seed, uint64_t offset,
+                                     sbl_stream_t stream) {
+    SegDesc d;
+    SBL_REQUIRE(sbl_make_segs(d, seg_L, nseg, B, H, Lk_fixed) > 0, "sbl_attention_seg_bwd: bad segment list (nseg=%d)", nseg);
+    if (int e = at_check("sbl_attention_bwd", B, H, d, Lk_fixed, ldq, ldk, ldv, lddo)) return e;
     SBL_REQUIRE(lddq >= H * 64 && lddk >= H * 64 && lddv >= H * 64, "sbl_attention_bwd: gradient row stride smaller than H*64");
     SBL_REQUIRE(dout && q && k && v && p && dq && dk && dv && sbl_aligned16(dout) && sbl_aligned16(q) && sbl_aligned16(k) && sbl_aligned16(v),
                 "sbl_attention_bwd: null/unaligned pointer");
     SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_attention_bwd: bad dropout args");
     const size_t lds = sizeof(float) * 6 * AT_SZ;
     static bool attr_set[64] = {false};
-    int dev = 0;
-    SBL_HIP(hipGetDevice(&dev));
-    if (!attr_set[dev & 63]) {
-        SBL_HIP(hipFuncSetAttribute((const void*)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev & 63] = true;
-    }
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, dout, lddo, q, ldq, k, ldk,
-                       v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk, scale,
+    if (int e = at_attr((const void*)attention_bwd_kernel, lds, attr_set)) return e;
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(nseg * B * H), dim3(256), lds, (hipStream_t)stream, dout, lddo, q, ldq, k, ldk,
+                       v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
                        drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset);
     SBL_LAUNCH_CHECK("sbl_attention_bwd");
     return 0;
+}
+
+// Uniform form (one segment): Lq query rows and Lk key rows per batch entry, q/k/v possibly different tensors.
+extern "C" int sbl_attention_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o,
+                                 long ldo, float* p_out, int mask_kind, const uint8_t* mask, int B, int H, int Lq, int Lk,
+                                 float scale, float drop_p, const uint64_t* seed, uint64_t offset, sbl_stream_t stream) {
+    SBL_REQUIRE(Lq >= 1 && Lk >= 1 && Lq <= 64 && Lk <= 64, "sbl_attention_fwd: need 1 <= Lq,Lk <= 64 (got %d,%d)", Lq, Lk);
+    return sbl_attention_seg_fwd(q, ldq, k, ldk, v, ldv, o, ldo, p_out, mask_kind, mask, B, H, &Lq, 1, Lk, scale, drop_p, seed,
+                                 offset, stream);
+}
+extern "C" int sbl_attention_bwd(const float* dout, long lddo, const float* q, long ldq, const float* k, long ldk,
+                                 const float* v, long ldv, const float* p, float* dq, long lddq, float* dk, long lddk,
+                                 float* dv, long lddv, int B, int H, int Lq, int Lk, float scale, float drop_p,
+                                 const uint64_t* seed, uint64_t offset, sbl_stream_t stream) {
+    SBL_REQUIRE(Lq >= 1 && Lk >= 1 && Lq <= 64 && Lk <= 64, "sbl_attention_bwd: need 1 <= Lq,Lk <= 64 (got %d,%d)", Lq, Lk);
+    return sbl_attention_seg_bwd(dout, lddo, q, ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, &Lq, 1, Lk, scale,
+                                 drop_p, seed, offset, stream);
 }

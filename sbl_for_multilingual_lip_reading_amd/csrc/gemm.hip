@@ -1,5 +1,6 @@
 // Dense fp32 GEMM entry points (nn.Linear forward / input-grad / weight-grad, bias grads).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "mfma_gemm.h"
 #include "skinny_gemm.h"
@@ -104,8 +105,10 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
     // split K when the output has too few 64x64 tiles to fill 256 CUs: aim at ~256 workgroups, chunks of at
     // least one 64-deep macro step, at most 8 slices (the last-arriving workgroup reads every slab)
     int splits = 1;
-    if (!big && tiles64 < 192 && K >= 128) {
-        splits = (int)((256 + tiles64 - 1) / tiles64);
+    static const int split_tiles = getenv("SBL_SPLIT_TILES") ? atoi(getenv("SBL_SPLIT_TILES")) : 192;   // tuning knobs
+    static const int split_target = getenv("SBL_SPLIT_TARGET") ? atoi(getenv("SBL_SPLIT_TARGET")) : 256;
+    if (!big && tiles64 < split_tiles && K >= 128) {
+        splits = (int)((split_target + tiles64 - 1) / tiles64);
         if (splits > K / 64) splits = K / 64;
         if (splits > 8) splits = 8;
         if (splits < 1) splits = 1;
@@ -130,7 +133,9 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
         const bool al_ok = (!a_kc || (sbl_aligned16(A) && lda % 4 == 0)) && (!b_kc || (sbl_aligned16(B) && ldb % 4 == 0));
         const bool k_ok = (!a_kc && !b_kc) || (K % 8 == 0);
         const long tiles32 = (long)sbl_cdiv(M, 32) * sbl_cdiv(N, 32);
-        const bool shape_ok = transA ? (K <= 512 && tiles32 <= 2048) : (M <= 512 && tiles32 <= 2048);
+        static const int max_m = getenv("SBL_SKINNY_MAX_M") ? atoi(getenv("SBL_SKINNY_MAX_M")) : 512;      // tuning knob
+        static const int max_t = getenv("SBL_SKINNY_MAX_TILES") ? atoi(getenv("SBL_SKINNY_MAX_TILES")) : 2048;
+        const bool shape_ok = transA ? (K <= max_m && tiles32 <= max_t) : (M <= max_m && tiles32 <= max_t);
         if (shape_ok && al_ok && k_ok && !(transA && transB)) {
             SkinnyEpi e{C, ldc, bias, relu, relu_mask, ldm, accumulate, a_colsum, sbl_next_stamp_slot(SBL_KID_SKINNY)};
             if (!transA && transB) sbl_launch_skinny<true, true>(A, lda, B, ldb, e, M, N, K, s);
@@ -147,11 +152,52 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
         if (vec) SBL_GO(true, 128, 128, 1);
         else SBL_GO(false, 128, 128, 1);
     } else {
-        if (vec) SBL_GO(true, 64, 64, 4);
-        else SBL_GO(false, 64, 64, 1);
+        static const int ku = getenv("SBL_TILED_KU") ? atoi(getenv("SBL_TILED_KU")) : 4;      // tuning knob
+        if (!vec) SBL_GO(false, 64, 64, 1);
+        else if (ku == 1) SBL_GO(true, 64, 64, 1);
+        else if (ku == 2) SBL_GO(true, 64, 64, 2);
+        else SBL_GO(true, 64, 64, 4);
     }
 #undef SBL_GO
     SBL_LAUNCH_CHECK("sbl_gemm_f32");
+    return 0;
+}
+
+// ------------------------------------------------------------------ deferred weight gradient over all decoder stages
+// C[M,N] += sum_s A_s^T B_s  (A_s: rows_s x M, B_s: rows_s x N, row-major), a_colsum[m] += column sums of A.
+// One launch per weight per step; split-K with float atomics (C is the persistent gradient buffer).
+extern "C" int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda, const float* const* B_ptrs, long ldb,
+                                 const int* seg_rows, int M, int N, float* C, long ldc, float* a_colsum,
+                                 sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(nseg >= 1 && nseg <= SBL_MAX_KSEG && A_ptrs && B_ptrs && seg_rows && C, "sbl_wgrad_seg_f32: bad segment list (nseg=%d)", nseg);
+    SBL_REQUIRE(M > 0 && N > 0 && lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0, "sbl_wgrad_seg_f32: bad dims M=%d N=%d lda=%ld ldb=%ld", M, N, lda, ldb);
+    SegMC<64> al, bl;
+    long K = 0;
+    for (int t = 0; t < SBL_MAX_KSEG; ++t) {
+        al.kcum[t] = bl.kcum[t] = (int)K;
+        if (t < nseg) {
+            SBL_REQUIRE(A_ptrs[t] && B_ptrs[t] && seg_rows[t] > 0 && sbl_aligned16(A_ptrs[t]) && sbl_aligned16(B_ptrs[t]), "sbl_wgrad_seg_f32: segment %d null/unaligned/empty", t);
+            al.p[t] = A_ptrs[t];
+            bl.p[t] = B_ptrs[t];
+            K += seg_rows[t];
+        } else {
+            al.p[t] = bl.p[t] = nullptr;
+        }
+    }
+    SBL_REQUIRE(K < (1L << 30), "sbl_wgrad_seg_f32: too many rows");
+    al.kcum[SBL_MAX_KSEG] = bl.kcum[SBL_MAX_KSEG] = (int)K;
+    al.nseg = bl.nseg = nseg;
+    al.ld = lda; bl.ld = ldb;
+    al.rows = M; bl.rows = N;
+    const long tiles = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
+    int splits = (int)((768 + tiles - 1) / tiles);          // ~3 workgroups per CU; chunks >= 128 rows
+    if (splits > K / 128) splits = (int)(K / 128);
+    if (splits < 1) splits = 1;
+    EpiStore<2, false> e{C, ldc, nullptr, 0, nullptr, nullptr, 0};
+    SplitCtl sc{nullptr, nullptr, a_colsum, sbl_next_stamp_slot(SBL_KID_TILED64)};
+    sbl_launch_gemm<SegMC<64>, SegMC<64>, EpiStore<2, false>, 64, 64, 2>(al, bl, e, M, N, (int)K, splits, s, sc);
+    SBL_LAUNCH_CHECK("sbl_wgrad_seg_f32");
     return 0;
 }
 

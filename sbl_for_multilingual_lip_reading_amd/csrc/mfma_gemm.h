@@ -132,6 +132,69 @@ struct DenseMC {
     }
 };
 
+// Segmented m-contiguous operand: the GEMM-k axis is the concatenation of up to 16 row blocks that live in
+// different tensors (the per-stage activations / gradients of one decoder layer): element (r, k) = p[s][(k -
+// kcum[s])*ld + r] with s the segment containing k.  Lets one weight-gradient GEMM contract over all decoder
+// stages of a step (K ~ 4352 rows) instead of one skinny GEMM per stage.
+#define SBL_MAX_KSEG 16
+template <int BR>
+struct SegMC {
+    static constexpr bool kColSum = true;
+    const float* p[SBL_MAX_KSEG];
+    int kcum[SBL_MAX_KSEG + 1];
+    int nseg;
+    long ld;
+    int rows;
+    static constexpr int TPR = BR / 4;
+    static constexpr int RPP = 256 / TPR;
+    static constexpr int NP = SBL_BK / RPP;
+    struct State {
+        int c, kr;
+    };
+    struct Regs {
+        float4 v[NP];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.c = r0 + (tid % TPR) * 4;
+        s.kr = tid / TPR;
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int k = k0 + s.kr + ps * RPP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend) {
+                int sg = 0;
+#pragma unroll
+                for (int t = 1; t < SBL_MAX_KSEG; ++t)
+                    if (t < nseg && k >= kcum[t]) sg = t;
+                const float* q = p[sg] + (long)(k - kcum[sg]) * ld + s.c;
+                if (s.c + 3 < rows) {
+                    v = *reinterpret_cast<const float4*>(q);
+                } else {
+                    if (s.c + 0 < rows) v.x = q[0];
+                    if (s.c + 1 < rows) v.y = q[1];
+                    if (s.c + 2 < rows) v.z = q[2];
+                    if (s.c + 3 < rows) v.w = q[3];
+                }
+            }
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void accum(const Regs& r, float4& cs) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            cs.x += r.v[ps].x; cs.y += r.v[ps].y; cs.z += r.v[ps].z; cs.w += r.v[ps].w;
+        }
+    }
+    __device__ __forceinline__ int col(const State& s) const { return s.c; }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
+    }
+};
+
 // NHWC convolution geometry (one struct for fwd / dgrad / wgrad gathers).
 //   "out" grid (OH,OW) indexes GEMM rows; "src" tensor (SH,SW,C) is what gets gathered.
 //   fwd / wgrad:  src = x (H,W,Cin),  out = y grid (Ho,Wo):   ih = oh*stride - pad + kh

@@ -9,15 +9,19 @@ static inline int ew_grid(long n) {
 }
 
 // ------------------------------------------------------------------ embedding + PE: decoder.py:116-120
+// Ragged form: segment s = decoder step with prefix length L[s]; its rows are (b, l), l < L[s], and every segment
+// reads the same token buffer tok[b*ldt + l] (a step's prefix is the first L tokens of the final sequence).
 __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __restrict__ tok, long ldt,
                                                            const float* __restrict__ emb, const float* __restrict__ pe,
-                                                           float* __restrict__ out, int B, int L, int D4, int V) {
-    const long n4 = (long)B * L * D4;
+                                                           float* __restrict__ out, int B, SegDesc segs, long rows, int D4,
+                                                           int V) {
+    const long n4 = rows * D4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % D4);
-        const long bl = i / D4;
-        const int l = (int)(bl % L);
-        const int b = (int)(bl / L);
+        const int r = (int)(i / D4);
+        const int s = sbl_seg_of_row(segs, r, B);
+        const int L = segs.L[s], rr = r - segs.row_off[s];
+        const int b = rr / L, l = rr - b * L;
         long t = tok[(long)b * ldt + l];
         t = t < 0 ? 0 : (t >= V ? V - 1 : t);   // ids are produced on-device from argmax/gold: always in range
         const float4 e = reinterpret_cast<const float4*>(emb)[t * D4 + c];
@@ -26,48 +30,68 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __rest
     }
 }
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, long ldt, const float* __restrict__ dy,
-                                                        float* __restrict__ demb, int B, int L, int D, int V) {
-    const long n = (long)B * L * D;
+                                                        float* __restrict__ demb, int B, SegDesc segs, long rows, int D, int V) {
+    const long n = rows * D;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c = (int)(i % D);
-        const long bl = i / D;
-        const int l = (int)(bl % L);
-        const int b = (int)(bl / L);
+        const int r = (int)(i / D);
+        const int s = sbl_seg_of_row(segs, r, B);
+        const int L = segs.L[s], rr = r - segs.row_off[s];
+        const int b = rr / L, l = rr - b * L;
         long t = tok[(long)b * ldt + l];
         t = t < 0 ? 0 : (t >= V ? V - 1 : t);
         atomicAdd(demb + t * D + c, dy[i]);
     }
 }
-extern "C" int sbl_embed_pe_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B, int L,
-                                int D, int V, sbl_stream_t stream) {
-    SBL_REQUIRE(tok && emb && pe && out && B > 0 && L > 0 && D > 0 && D % 4 == 0 && V > 0 && ldt >= L, "sbl_embed_pe_fwd: bad args");
+extern "C" int sbl_embed_pe_seg_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B,
+                                    const int* seg_L, int nseg, int D, int V, sbl_stream_t stream) {
+    SegDesc d;
+    const long rows = sbl_make_segs(d, seg_L, nseg, B, 1, 1);
+    SBL_REQUIRE(rows > 0, "sbl_embed_pe_seg_fwd: bad segment list");
+    SBL_REQUIRE(tok && emb && pe && out && B > 0 && D > 0 && D % 4 == 0 && V > 0, "sbl_embed_pe_fwd: bad args");
+    for (int s = 0; s < nseg; ++s) SBL_REQUIRE(ldt >= seg_L[s], "sbl_embed_pe_fwd: token row shorter than prefix %d", seg_L[s]);
     SBL_REQUIRE(sbl_aligned16(emb) && sbl_aligned16(pe) && sbl_aligned16(out), "sbl_embed_pe_fwd: unaligned");
-    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(ew_grid((long)B * L * D / 4)), dim3(256), 0, (hipStream_t)stream, tok, ldt,
-                       emb, pe, out, B, L, D / 4, V);
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(ew_grid(rows * D / 4)), dim3(256), 0, (hipStream_t)stream, tok, ldt, emb, pe,
+                       out, B, d, rows, D / 4, V);
     SBL_LAUNCH_CHECK("sbl_embed_pe_fwd");
     return 0;
 }
-extern "C" int sbl_embed_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, int L, int D, int V,
-                             sbl_stream_t stream) {
-    SBL_REQUIRE(tok && dy && demb && B > 0 && L > 0 && D > 0 && V > 0 && ldt >= L, "sbl_embed_bwd: bad args");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((long)B * L * D)), dim3(256), 0, (hipStream_t)stream, tok, ldt, dy,
-                       demb, B, L, D, V);
+extern "C" int sbl_embed_seg_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, const int* seg_L, int nseg,
+                                 int D, int V, sbl_stream_t stream) {
+    SegDesc d;
+    const long rows = sbl_make_segs(d, seg_L, nseg, B, 1, 1);
+    SBL_REQUIRE(rows > 0, "sbl_embed_seg_bwd: bad segment list");
+    SBL_REQUIRE(tok && dy && demb && B > 0 && D > 0 && V > 0, "sbl_embed_bwd: bad args");
+    for (int s = 0; s < nseg; ++s) SBL_REQUIRE(ldt >= seg_L[s], "sbl_embed_bwd: token row shorter than prefix %d", seg_L[s]);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid(rows * D)), dim3(256), 0, (hipStream_t)stream, tok, ldt, dy, demb, B, d,
+                       rows, D, V);
     SBL_LAUNCH_CHECK("sbl_embed_bwd");
     return 0;
+}
+extern "C" int sbl_embed_pe_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B, int L,
+                                int D, int V, sbl_stream_t stream) {
+    return sbl_embed_pe_seg_fwd(tok, ldt, emb, pe, out, B, &L, 1, D, V, stream);
+}
+extern "C" int sbl_embed_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, int L, int D, int V,
+                             sbl_stream_t stream) {
+    return sbl_embed_seg_bwd(tok, ldt, dy, demb, B, &L, 1, D, V, stream);
 }
 
 // ------------------------------------------------------------------ SBL fusion: decoder.py:132-143,160-164
 // fwd: A' = A + flip(B), B' = 2B + flip(A).  bwd (adjoint): dA = dA' + flip(dB'), dB = flip(dA') + 2 dB'.
+// The flip runs along each sequence's own prefix axis (per segment, per batch row).
 template <bool BWD>
 __global__ __launch_bounds__(256) void fusion_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                     float* __restrict__ a2, float* __restrict__ b2, int B, int L, int D4) {
-    const long n4 = (long)B * L * D4;
+                                                     float* __restrict__ a2, float* __restrict__ b2, int B, SegDesc segs,
+                                                     long rows, int D4) {
+    const long n4 = rows * D4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % D4);
-        const long bl = i / D4;
-        const int l = (int)(bl % L);
-        const long bb = bl / L;
-        const long f = (bb * L + (L - 1 - l)) * D4 + c;   // time-flipped position
+        const int r = (int)(i / D4);
+        const int s = sbl_seg_of_row(segs, r, B);
+        const int L = segs.L[s], rr = r - segs.row_off[s];
+        const int l = rr % L;
+        const long f = ((long)r + (L - 1 - 2 * l)) * D4 + c;   // time-flipped position inside the same sequence
         const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
         const float4 xf = reinterpret_cast<const float4*>(a)[f], yf = reinterpret_cast<const float4*>(b)[f];
         float4 o1, o2;
@@ -82,22 +106,68 @@ __global__ __launch_bounds__(256) void fusion_kernel(const float* __restrict__ a
         reinterpret_cast<float4*>(b2)[i] = o2;
     }
 }
-static int fusion_common(const char* who, const float* a, const float* b, float* a2, float* b2, int B, int L, int D,
-                         bool bwd, sbl_stream_t stream) {
-    SBL_REQUIRE(a && b && a2 && b2 && B > 0 && L > 0 && D > 0 && D % 4 == 0, "%s: bad args", who);
+static int fusion_common(const char* who, const float* a, const float* b, float* a2, float* b2, int B, const int* seg_L,
+                         int nseg, int D, bool bwd, sbl_stream_t stream) {
+    SegDesc d;
+    const long rows = sbl_make_segs(d, seg_L, nseg, B, 1, 1);
+    SBL_REQUIRE(rows > 0, "%s: bad segment list", who);
+    SBL_REQUIRE(a && b && a2 && b2 && B > 0 && D > 0 && D % 4 == 0, "%s: bad args", who);
     SBL_REQUIRE(a2 != a && a2 != b && b2 != a && b2 != b && a2 != b2, "%s: outputs must not alias inputs (time flip)", who);
     SBL_REQUIRE(sbl_aligned16(a) && sbl_aligned16(b) && sbl_aligned16(a2) && sbl_aligned16(b2), "%s: unaligned", who);
-    const long n4 = (long)B * L * D / 4;
-    if (bwd) hipLaunchKernelGGL(fusion_kernel<true>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, a2, b2, B, L, D / 4);
-    else hipLaunchKernelGGL(fusion_kernel<false>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, a2, b2, B, L, D / 4);
+    const long n4 = rows * D / 4;
+    if (bwd) hipLaunchKernelGGL(fusion_kernel<true>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, a2, b2, B, d, rows, D / 4);
+    else hipLaunchKernelGGL(fusion_kernel<false>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, a2, b2, B, d, rows, D / 4);
     SBL_LAUNCH_CHECK(who);
     return 0;
 }
+extern "C" int sbl_fusion_seg_fwd(const float* a, const float* b, float* a2, float* b2, int B, const int* seg_L, int nseg,
+                                  int D, sbl_stream_t stream) {
+    return fusion_common("sbl_fusion_fwd", a, b, a2, b2, B, seg_L, nseg, D, false, stream);
+}
+extern "C" int sbl_fusion_seg_bwd(const float* da2, const float* db2, float* da, float* db, int B, const int* seg_L, int nseg,
+                                  int D, sbl_stream_t stream) {
+    return fusion_common("sbl_fusion_bwd", da2, db2, da, db, B, seg_L, nseg, D, true, stream);
+}
 extern "C" int sbl_fusion_fwd(const float* a, const float* b, float* a2, float* b2, int B, int L, int D, sbl_stream_t stream) {
-    return fusion_common("sbl_fusion_fwd", a, b, a2, b2, B, L, D, false, stream);
+    return fusion_common("sbl_fusion_fwd", a, b, a2, b2, B, &L, 1, D, false, stream);
 }
 extern "C" int sbl_fusion_bwd(const float* da2, const float* db2, float* da, float* db, int B, int L, int D, sbl_stream_t stream) {
-    return fusion_common("sbl_fusion_bwd", da2, db2, da, db, B, L, D, true, stream);
+    return fusion_common("sbl_fusion_bwd", da2, db2, da, db, B, &L, 1, D, true, stream);
+}
+
+// ------------------------------------------------------------------ last position of every sequence: decoder.py:166-167
+// out[s*B + b, :] = x[row_off[s] + b*L[s] + L[s]-1, :]   (the rows the two output heads read); bwd scatters back.
+template <bool BWD>
+__global__ __launch_bounds__(256) void gather_last_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                          SegDesc segs, int D4) {
+    const long n4 = (long)segs.nseg * B * D4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const int sb = (int)(i / D4);
+        const int s = sb / B, b = sb - s * B;
+        const long row = segs.row_off[s] + (long)b * segs.L[s] + segs.L[s] - 1;
+        if (!BWD) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[row * D4 + c];
+        else reinterpret_cast<float4*>(dst)[row * D4 + c] = reinterpret_cast<const float4*>(src)[i];
+    }
+}
+extern "C" int sbl_gather_last_fwd(const float* x, float* out, int B, const int* seg_L, int nseg, int D, sbl_stream_t stream) {
+    SegDesc d;
+    SBL_REQUIRE(sbl_make_segs(d, seg_L, nseg, B, 1, 1) > 0, "sbl_gather_last_fwd: bad segment list");
+    SBL_REQUIRE(x && out && B > 0 && D > 0 && D % 4 == 0 && sbl_aligned16(x) && sbl_aligned16(out), "sbl_gather_last_fwd: bad args");
+    hipLaunchKernelGGL(gather_last_kernel<false>, dim3(ew_grid((long)nseg * B * D / 4)), dim3(256), 0, (hipStream_t)stream, x, out, B, d, D / 4);
+    SBL_LAUNCH_CHECK("sbl_gather_last_fwd");
+    return 0;
+}
+// dx (rows x D) is zero-filled by the call, then the nseg*B gradient rows are scattered into it
+extern "C" int sbl_gather_last_bwd(const float* dy, float* dx, int B, const int* seg_L, int nseg, int D, sbl_stream_t stream) {
+    SegDesc d;
+    const long rows = sbl_make_segs(d, seg_L, nseg, B, 1, 1);
+    SBL_REQUIRE(rows > 0, "sbl_gather_last_bwd: bad segment list");
+    SBL_REQUIRE(dy && dx && B > 0 && D > 0 && D % 4 == 0 && sbl_aligned16(dy) && sbl_aligned16(dx), "sbl_gather_last_bwd: bad args");
+    SBL_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)rows * D, (hipStream_t)stream));
+    hipLaunchKernelGGL(gather_last_kernel<true>, dim3(ew_grid((long)nseg * B * D / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, d, D / 4);
+    SBL_LAUNCH_CHECK("sbl_gather_last_bwd");
+    return 0;
 }
 
 // ------------------------------------------------------------------ token feedback: decoder.py:173-186
@@ -136,7 +206,8 @@ __global__ __launch_bounds__(256) void argmax_select_kernel(const float* __restr
 }
 extern "C" int sbl_argmax_select(const float* pred, long ldp, const int64_t* gold, long ldg, int64_t* ys, long ldy, int step,
                                  int use_argmax, const int32_t* coins_dev, int B, int V, sbl_stream_t stream) {
-    SBL_REQUIRE(pred && ys && B > 0 && V > 0 && ldp >= V && step >= 0 && step + 1 < ldy, "sbl_argmax_select: bad args");
+    SBL_REQUIRE(ys && B > 0 && V > 0 && ldp >= V && step >= 0 && step + 1 < ldy, "sbl_argmax_select: bad args");
+    SBL_REQUIRE(pred || (!use_argmax && !coins_dev), "sbl_argmax_select: logits required unless the token is the gold one");
     SBL_REQUIRE(gold || (use_argmax && !coins_dev), "sbl_argmax_select: gold required unless always-argmax");
     SBL_REQUIRE(!gold || step < ldg, "sbl_argmax_select: step beyond gold width");
     hipLaunchKernelGGL(argmax_select_kernel, dim3(sbl_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, pred, ldp, gold, ldg,

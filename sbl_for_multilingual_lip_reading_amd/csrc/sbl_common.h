@@ -54,6 +54,42 @@ __device__ __forceinline__ void sbl_stamp_end(unsigned long long* slot) {
 #define SBL_KID_CONV_DGRAD 5
 #define SBL_KID_CONV_WGRAD 6
 
+// ---- ragged row batches: a "run" of decoder steps whose inputs are all known is processed as one batch of
+// segments; segment s holds B sequences of length L[s], rows [row_off[s], row_off[s] + B*L[s]) in (b, l) order.
+#define SBL_MAX_SEG 16
+struct SegDesc {
+    int nseg;
+    int L[SBL_MAX_SEG];
+    int row_off[SBL_MAX_SEG];
+    int p_off[SBL_MAX_SEG];     // offset (floats) of the segment's attention-probability block
+};
+// host: build from an array of lengths; returns total rows (or -1 on bad input)
+static inline long sbl_make_segs(SegDesc& d, const int* seg_L, int nseg, int B, int H, int Lk_fixed) {
+    if (nseg < 1 || nseg > SBL_MAX_SEG || !seg_L) return -1;
+    d.nseg = nseg;
+    long rows = 0, p = 0;
+    for (int s = 0; s < SBL_MAX_SEG; ++s) {
+        d.L[s] = s < nseg ? seg_L[s] : 0;
+        d.row_off[s] = (int)rows;
+        d.p_off[s] = (int)p;
+        if (s < nseg) {
+            if (seg_L[s] < 1) return -1;
+            rows += (long)B * seg_L[s];
+            p += (long)H * B * seg_L[s] * (Lk_fixed > 0 ? Lk_fixed : seg_L[s]);
+            if (rows > (1L << 30) || p > (1L << 30)) return -1;
+        }
+    }
+    return rows;
+}
+// device: segment containing row r
+__device__ __forceinline__ int sbl_seg_of_row(const SegDesc& d, int r, int B) {
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < SBL_MAX_SEG; ++t)
+        if (t < d.nseg && r >= d.row_off[t]) s = t;
+    return s;
+}
+
 static inline int sbl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool sbl_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -134,9 +134,71 @@ def _aux_for(cur):
     return st
 
 
-def wgrad_gemm(M, N, K, A, lda, B, ldb, C, ldc, acc, colsum):
-    """dW (+)= A^T B with the bias gradient riding on it.  When the destination is a persistent gradient buffer
-    (acc=1) the launch goes to the auxiliary stream; the operands are pinned for that stream."""
+class WgradCollector:
+    """Deferred weight gradients of the decoder.  Every decoder weight is used once per stage (up to 16 times per
+    step); instead of one skinny dW GEMM per use inside backward's dependency chain, the (dY, X) operand pairs are
+    collected and each weight gets ONE GEMM that contracts over all stages' rows (K ~ 4352) when backward has
+    finished (autograd engine callback).  Needs persistent gradient buffers (dp.FlatModel)."""
+
+    def __init__(self):
+        self.entries = {}
+        self.armed = False
+
+    def add(self, C, ldc, colsum, A, lda, B, ldb, rows, M, N):
+        e = self.entries.get(C.data_ptr())
+        if e is None:
+            e = self.entries[C.data_ptr()] = {"C": C, "ldc": ldc, "colsum": colsum, "lda": lda, "ldb": ldb, "M": M,
+                                              "N": N, "A": [], "B": [], "rows": []}
+        e["A"].append(A)
+        e["B"].append(B)
+        e["rows"].append(rows)
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        cur = torch.cuda.current_stream()
+        side = _side_streams.get(cur.device_index)
+        if side is not None:
+            cur.wait_stream(side)              # operands produced by the other direction's stream
+        for e in self.entries.values():
+            n = len(e["rows"])
+            for i in range(0, n, 16):
+                A, B, rows = e["A"][i:i + 16], e["B"][i:i + 16], e["rows"][i:i + 16]
+                k = len(rows)
+                pa = (_ct.c_void_p * k)(*[t.data_ptr() for t in A])
+                pb = (_ct.c_void_p * k)(*[t.data_ptr() for t in B])
+                pr = (_ct.c_int * k)(*rows)
+                call("sbl_wgrad_seg_f32", k, pa, e["lda"], pb, e["ldb"], pr, e["M"], e["N"], _p(e["C"]), e["ldc"],
+                     _p(e["colsum"]), _s())
+            for t in e["A"] + e["B"]:
+                t.record_stream(cur)
+        self.entries = {}
+        self.armed = False
+
+
+DEFER_WGRAD = os.environ.get("SBL_DEFER_WGRAD", "1") != "0"
+_collector = None
+
+
+def begin_defer():
+    """Decoder forward: tape nodes created from here on defer their weight gradients (if enabled)."""
+    global _collector
+    _collector = WgradCollector() if DEFER_WGRAD else None
+
+
+def end_defer():
+    global _collector
+    _collector = None
+
+
+def wgrad_gemm(M, N, K, A, lda, B, ldb, C, ldc, acc, colsum, defer=None):
+    """dW (+)= A^T B with the bias gradient riding on it.  With a collector and a persistent gradient buffer (acc=1)
+    the product is deferred to one all-stages GEMM per weight; else it is issued now (optionally on the auxiliary
+    stream)."""
+    if defer is not None and acc:
+        defer.add(C, ldc, colsum, A, lda, B, ldb, K, M, N)
+        return
     if not (acc and OFFLOAD_WGRAD):
         gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, accumulate=acc, colsum=colsum)
         return
@@ -183,6 +245,20 @@ def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, relu=0, mask=None, 
     ws = _workspace()
     call("sbl_gemm_f32", ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), relu, _p(mask), ldm,
          accumulate, _p(colsum), ws.data_ptr(), WS_BYTES, _s())
+
+
+import ctypes as _ct
+
+_seg_arrays = {}
+
+
+def _segs(segL):
+    """host int array of prefix lengths for the ragged ("segmented") kernels, cached per tuple"""
+    segL = tuple(int(v) for v in segL)
+    arr = _seg_arrays.get(segL)
+    if arr is None:
+        arr = _seg_arrays[segL] = (_ct.c_int * len(segL))(*segL)
+    return arr, len(segL)
 
 
 def _gbuf(p):
@@ -474,11 +550,14 @@ class MHAFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, kv, wq, bq, wk, bk, wv, bv, wfc, bfc, gamma, beta, H, mask_kind, mask_t, drop_p, eps):
+    def forward(ctx, x, kv, wq, bq, wk, bk, wv, bv, wfc, bfc, gamma, beta, H, mask_kind, mask_t, drop_p, eps, B, segL):
+        """x: (R, D) rows of a ragged batch: segment s has B sequences of length segL[s] (one segment = the plain
+        (B, L, D) case).  Returns (y (R, D), p = the segments' (H*B, L, Lk) probability blocks back to back)."""
         _need_cuda(x, wq, wfc)
-        B, Lq, D = x.shape
-        x2 = x.contiguous().view(B * Lq, D)
-        M = B * Lq
+        x2 = x.contiguous()
+        M, D = x2.shape
+        assert M == B * sum(segL), (M, B, segL)
+        seg_arr, nseg = _segs(segL)
         HD = H * 64
         dev = x.device
         self_attn = kv is None
@@ -488,7 +567,8 @@ class MHAFn(torch.autograd.Function):
             gemm(0, 1, M, 3 * HD, D, x2, D, wq, D, qkv, 3 * HD, bias=bq)
             qp, kp, vp = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
             ldq = ldk = ldv = 3 * HD
-            Lk = Lq
+            Lk = 0                                   # keys = the segment's own rows
+            psize = H * B * sum(l * l for l in segL)
             gw, gb = (_gbuf(wq), _gbuf(wk), _gbuf(wv)), (_gbuf(bq), _gbuf(bk), _gbuf(bv))
             fused_ok = all(g is not None for g in gw + gb) and _adjacent(*gw) and _adjacent(*gb)
             g_qkv = (gw[0], gb[0]) if fused_ok else (None, None)
@@ -496,19 +576,20 @@ class MHAFn(torch.autograd.Function):
             qkv = torch.empty(M, HD, device=dev, dtype=torch.float32)
             gemm(0, 1, M, HD, D, x2, D, wq, D, qkv, HD, bias=bq)
             Lk = kv.size(0) // B
+            psize = H * B * sum(segL) * Lk
             qp, kp, vp = qkv, kv, kv[:, HD:]
             ldq, ldk, ldv = HD, 2 * HD, 2 * HD
             g_qkv = (_gbuf(wq), _gbuf(bq))
             if g_qkv[0] is None or g_qkv[1] is None:
                 g_qkv = (None, None)
         att = torch.empty(M, HD, device=dev, dtype=torch.float32)
-        p = torch.empty(H * B, Lq, Lk, device=dev, dtype=torch.float32)
+        p = torch.empty(psize, device=dev, dtype=torch.float32)
         seed, off_a, off_o = None, 0, 0
         if drop_p > 0:
             st = dropout_state(dev)
             seed, off_a, off_o = st.seed, st.next_offset(), st.next_offset()
-        call("sbl_attention_fwd", _p(qp), ldq, _p(kp), ldk, _p(vp), ldv, _p(att), HD, _p(p), mask_kind, _p(mask_t), B, H,
-             Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
+        call("sbl_attention_seg_fwd", _p(qp), ldq, _p(kp), ldk, _p(vp), ldv, _p(att), HD, _p(p), mask_kind, _p(mask_t), B, H,
+             seg_arr, nseg, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
         o = torch.empty(M, D, device=dev, dtype=torch.float32)
         gemm(0, 1, M, D, HD, att, HD, wfc, HD, o, D, bias=bfc)
         y = torch.empty(M, D, device=dev, dtype=torch.float32)
@@ -517,24 +598,26 @@ class MHAFn(torch.autograd.Function):
         call("sbl_add_layernorm_fwd", _p(o), _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, drop_p,
              _p(seed), off_o, _s())
         ctx.save_for_backward(x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed)
-        ctx.cfg = (B, Lq, Lk, D, H, drop_p, off_a, off_o, self_attn)
+        ctx.cfg = (B, tuple(segL), Lk, D, H, drop_p, off_a, off_o, self_attn)
         ctx.gb = (g_qkv, (_gbuf(wfc), _gbuf(bfc)), (_gbuf(gamma), _gbuf(beta)))
+        ctx.defer = _collector
         ctx.mark_non_differentiable(p)
-        return y.view(B, Lq, D), p
+        return y, p
 
     @staticmethod
     def backward(ctx, dy, _dp):
         x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed = ctx.saved_tensors
-        B, Lq, Lk, D, H, drop_p, off_a, off_o, self_attn = ctx.cfg
+        B, segL, Lk, D, H, drop_p, off_a, off_o, self_attn = ctx.cfg
         g_qkv, g_fc, g_ln = ctx.gb
-        M, HD, dev = B * Lq, H * 64, dy.device
+        seg_arr, nseg = _segs(segL)
+        M, HD, dev = B * sum(segL), H * 64, dy.device
         _xs_in(dy)
         dy2 = dy.contiguous().view(M, D)
         # LayerNorm(dropout(o) + x) adjoint: dz = grad of the residual x, do = grad of the pre-dropout o
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
         # a separate pre-dropout gradient buffer is also needed without dropout when the weight-gradient GEMM reads
         # it from the auxiliary stream while this stream accumulates the input gradient into dz in place
-        sep = drop_p > 0 or (OFFLOAD_WGRAD and g_fc[0] is not None)
+        sep = drop_p > 0 or ((OFFLOAD_WGRAD or ctx.defer is not None) and g_fc[0] is not None)
         do = torch.empty(M, D, device=dev, dtype=torch.float32) if sep else None
         dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
         dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
@@ -545,37 +628,37 @@ class MHAFn(torch.autograd.Function):
         # fc: dW (+ bias grad riding on it), then input gradient
         dwfc, acc, dwfc_ret = _target(g_fc[0], (D, HD), dev)
         dbfc, _, dbfc_ret = _target(g_fc[1], (D,), dev, zero=True)
-        wgrad_gemm(D, HD, M, do, D, att, HD, dwfc, HD, acc, dbfc)
+        wgrad_gemm(D, HD, M, do, D, att, HD, dwfc, HD, acc, dbfc, ctx.defer)
         datt = torch.empty(M, HD, device=dev, dtype=torch.float32)
         gemm(0, 0, M, HD, D, do, D, wfc, HD, datt, HD)
         dx = dz          # residual-branch gradient; the projection's input gradient accumulates on top of it
         if self_attn:
             dqkv = torch.empty(M, 3 * HD, device=dev, dtype=torch.float32)
             ld = 3 * HD
-            call("sbl_attention_bwd", _p(datt), HD, _p(qkv), ld, _p(qkv[:, HD:]), ld, _p(qkv[:, 2 * HD:]), ld, _p(p),
-                 _p(dqkv), ld, _p(dqkv[:, HD:]), ld, _p(dqkv[:, 2 * HD:]), ld, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed),
-                 off_a, _s())
+            call("sbl_attention_seg_bwd", _p(datt), HD, _p(qkv), ld, _p(qkv[:, HD:]), ld, _p(qkv[:, 2 * HD:]), ld, _p(p),
+                 _p(dqkv), ld, _p(dqkv[:, HD:]), ld, _p(dqkv[:, 2 * HD:]), ld, B, H, seg_arr, nseg, 0, 1.0 / 8.0, drop_p,
+                 _p(seed), off_a, _s())
             dw, acc, dw_ret = _target(g_qkv[0], (3 * HD, D), dev)
             db, _, db_ret = _target(g_qkv[1], (3 * HD,), dev, zero=True)
-            wgrad_gemm(3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D, acc, db)
+            wgrad_gemm(3 * HD, D, M, dqkv, 3 * HD, x2, D, dw, D, acc, db, ctx.defer)
             gemm(0, 0, M, D, 3 * HD, dqkv, 3 * HD, wq, D, dx, D, accumulate=1)
             if dw_ret is None:
                 wret = (None,) * 6
             else:
                 wret = (dw_ret[:HD], db_ret[:HD], dw_ret[HD:2 * HD], db_ret[HD:2 * HD], dw_ret[2 * HD:], db_ret[2 * HD:])
             _xs_out(dx)
-            return (dx.view(B, Lq, D), None) + wret + (dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret, None, None, None, None, None)
+            return (dx, None) + wret + (dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret) + (None,) * 7
         dq = torch.empty(M, HD, device=dev, dtype=torch.float32)
-        dkv = torch.empty(B * Lk, 2 * HD, device=dev, dtype=torch.float32)
-        call("sbl_attention_bwd", _p(datt), HD, _p(qkv), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(p), _p(dq), HD,
-             _p(dkv), 2 * HD, _p(dkv[:, HD:]), 2 * HD, B, H, Lq, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
+        # several segments share the keys/values: their dK/dV contributions are atomically accumulated
+        dkv = (torch.zeros if nseg > 1 else torch.empty)(B * Lk, 2 * HD, device=dev, dtype=torch.float32)
+        call("sbl_attention_seg_bwd", _p(datt), HD, _p(qkv), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(p), _p(dq), HD,
+             _p(dkv), 2 * HD, _p(dkv[:, HD:]), 2 * HD, B, H, seg_arr, nseg, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
         dwq, acc, dwq_ret = _target(g_qkv[0], (HD, D), dev)
         dbq, _, dbq_ret = _target(g_qkv[1], (HD,), dev, zero=True)
-        wgrad_gemm(HD, D, M, dq, HD, x2, D, dwq, D, acc, dbq)
+        wgrad_gemm(HD, D, M, dq, HD, x2, D, dwq, D, acc, dbq, ctx.defer)
         gemm(0, 0, M, D, HD, dq, HD, wq, D, dx, D, accumulate=1)
         _xs_out(dx, dkv)
-        return (dx.view(B, Lq, D), dkv, dwq_ret, dbq_ret, None, None, None, None, dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret,
-                None, None, None, None, None)
+        return (dx, dkv, dwq_ret, dbq_ret, None, None, None, None, dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret) + (None,) * 7
 
 
 class FFNFn(torch.autograd.Function):
@@ -605,6 +688,7 @@ class FFNFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h, o, mean, rstd, w1, w2, gamma, seed)
         ctx.cfg = (shp, drop_p, off)
         ctx.gb = ((_gbuf(w1), _gbuf(b1)), (_gbuf(w2), _gbuf(b2)), (_gbuf(gamma), _gbuf(beta)))
+        ctx.defer = _collector
         return y.view(shp)
 
     @staticmethod
@@ -619,7 +703,7 @@ class FFNFn(torch.autograd.Function):
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
         # a separate pre-dropout gradient buffer is also needed without dropout when the weight-gradient GEMM reads
         # it from the auxiliary stream while this stream accumulates the input gradient into dz in place
-        sep = drop_p > 0 or (OFFLOAD_WGRAD and g2[0] is not None)
+        sep = drop_p > 0 or ((OFFLOAD_WGRAD or ctx.defer is not None) and g2[0] is not None)
         do = torch.empty(M, D, device=dev, dtype=torch.float32) if sep else None
         dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
         dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
@@ -629,12 +713,12 @@ class FFNFn(torch.autograd.Function):
             do = dz
         dw2, acc, dw2_ret = _target(g2[0], (D, F_), dev)
         db2, _, db2_ret = _target(g2[1], (D,), dev, zero=True)
-        wgrad_gemm(D, F_, M, do, D, h, F_, dw2, F_, acc, db2)
+        wgrad_gemm(D, F_, M, do, D, h, F_, dw2, F_, acc, db2, ctx.defer)
         dh = torch.empty(M, F_, device=dev, dtype=torch.float32)
         gemm(0, 0, M, F_, D, do, D, w2, F_, dh, F_, mask=h, ldm=F_)      # ReLU adjoint fused in the epilogue
         dw1, acc, dw1_ret = _target(g1[0], (F_, D), dev)
         db1, _, db1_ret = _target(g1[1], (F_,), dev, zero=True)
-        wgrad_gemm(F_, D, M, dh, F_, x2, D, dw1, D, acc, db1)
+        wgrad_gemm(F_, D, M, dh, F_, x2, D, dw1, D, acc, db1, ctx.defer)
         dx = dz
         gemm(0, 0, M, D, F_, dh, F_, w1, D, dx, D, accumulate=1)
         _xs_out(dx)
@@ -645,17 +729,18 @@ class FFNFn(torch.autograd.Function):
 # decoder pieces
 # --------------------------------------------------------------------------- #
 class EmbedPEFn(torch.autograd.Function):
-    """emb[tok] + pe[:L]; decoder.py:116-120 (x_logit_scale = 1)."""
+    """emb[tok] + pe[:L] for every segment (decoder step) of a run; decoder.py:116-120 (x_logit_scale = 1).
+    tok: (B, 17) device token buffer; segment s embeds its first segL[s] columns.  Returns (B*sum(segL), D)."""
 
     @staticmethod
-    def forward(ctx, tok, L, emb, pe):
+    def forward(ctx, tok, B, segL, emb, pe):
         _need_cuda(tok, emb, pe)
-        B = tok.size(0)
         V, D = emb.shape
-        out = torch.empty(B, L, D, device=emb.device, dtype=torch.float32)
-        call("sbl_embed_pe_fwd", _p(tok), tok.stride(0), _p(emb), _p(pe), _p(out), B, L, D, V, _s())
-        # tokens are written in place by later steps, but positions < L never change again
-        ctx.tok, ctx.L, ctx.shape = tok, L, (V, D)
+        seg_arr, nseg = _segs(segL)
+        out = torch.empty(B * sum(segL), D, device=emb.device, dtype=torch.float32)
+        call("sbl_embed_pe_seg_fwd", _p(tok), tok.stride(0), _p(emb), _p(pe), _p(out), B, seg_arr, nseg, D, V, _s())
+        # tokens are written in place by later steps, but positions inside an already embedded prefix never change
+        ctx.tok, ctx.B, ctx.segL, ctx.shape = tok, B, tuple(segL), (V, D)
         ctx.gb = _gbuf(emb)
         return out
 
@@ -663,36 +748,71 @@ class EmbedPEFn(torch.autograd.Function):
     def backward(ctx, dy):
         V, D = ctx.shape
         dy = dy.contiguous()
+        seg_arr, nseg = _segs(ctx.segL)
         demb, _, demb_ret = _target(ctx.gb, (V, D), dy.device, zero=True)
-        call("sbl_embed_bwd", _p(ctx.tok), ctx.tok.stride(0), _p(dy), _p(demb), dy.size(0), ctx.L, D, V, _s())
-        return None, None, demb_ret, None
+        call("sbl_embed_seg_bwd", _p(ctx.tok), ctx.tok.stride(0), _p(dy), _p(demb), ctx.B, seg_arr, nseg, D, V, _s())
+        return None, None, None, demb_ret, None
 
 
 class FusionFn(torch.autograd.Function):
-    """A' = A + flip(B), B' = 2B + flip(A); decoder.py:132-143,160-164 (closed form)."""
+    """A' = A + flip(B), B' = 2B + flip(A) along each sequence's own prefix; decoder.py:132-143,160-164
+    (closed form).  a, b: (B*sum(segL), D) rows, or (B, L, D) with segL=None."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, B=None, segL=None):
         _need_cuda(a, b)
         a, b = a.contiguous(), b.contiguous()
-        B, L, D = a.shape
+        if segL is None:
+            B, segL = a.size(0), (a.size(1),)
+        D = a.size(-1)
+        seg_arr, nseg = _segs(segL)
         a2, b2 = torch.empty_like(a), torch.empty_like(b)
-        call("sbl_fusion_fwd", _p(a), _p(b), _p(a2), _p(b2), B, L, D, _s())
+        call("sbl_fusion_seg_fwd", _p(a), _p(b), _p(a2), _p(b2), B, seg_arr, nseg, D, _s())
+        ctx.cfg = (B, tuple(segL), D)
         return a2, b2
 
     @staticmethod
     def backward(ctx, da2, db2):
+        B, segL, D = ctx.cfg
         da2, db2 = da2.contiguous(), db2.contiguous()
-        B, L, D = da2.shape
+        seg_arr, nseg = _segs(segL)
         da, db = torch.empty_like(da2), torch.empty_like(db2)
-        call("sbl_fusion_bwd", _p(da2), _p(db2), _p(da), _p(db), B, L, D, _s())
-        return da, db
+        call("sbl_fusion_seg_bwd", _p(da2), _p(db2), _p(da), _p(db), B, seg_arr, nseg, D, _s())
+        return da, db, None, None
+
+
+class GatherLastFn(torch.autograd.Function):
+    """The last position of every sequence of a ragged batch, (nseg*B, D): the rows the heads read, decoder.py:166-167."""
+
+    @staticmethod
+    def forward(ctx, x, B, segL):
+        _need_cuda(x)
+        x = x.contiguous()
+        D = x.size(-1)
+        seg_arr, nseg = _segs(segL)
+        out = torch.empty(nseg * B, D, device=x.device, dtype=torch.float32)
+        call("sbl_gather_last_fwd", _p(x), _p(out), B, seg_arr, nseg, D, _s())
+        ctx.cfg = (B, tuple(segL), D, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, segL, D, shp = ctx.cfg
+        dy = dy.contiguous()
+        seg_arr, nseg = _segs(segL)
+        dx = torch.empty(shp, device=dy.device, dtype=torch.float32)
+        call("sbl_gather_last_bwd", _p(dy), _p(dx), B, seg_arr, nseg, D, _s())
+        return dx, None, None
 
 
 def argmax_select(pred, gold, ys, step, use_argmax, coins_dev=None):
     """ys[:, step+1] = argmax(pred) if coin else gold[:, step]; decoder.py:173-186, on the device."""
-    B, V = pred.shape
-    call("sbl_argmax_select", _p(pred), pred.stride(0), _p(gold), 0 if gold is None else gold.stride(0), _p(ys),
+    if pred is None:                       # pure teacher token (no logits needed)
+        assert not use_argmax and coins_dev is None and gold is not None
+        B, V, ldp = ys.size(0), 1, 1
+    else:
+        (B, V), ldp = pred.shape, pred.stride(0)
+    call("sbl_argmax_select", _p(pred), ldp, _p(gold), 0 if gold is None else gold.stride(0), _p(ys),
          ys.stride(0), step, int(use_argmax), _p(coins_dev), B, V, _s())
 
 

@@ -67,27 +67,41 @@ class MultiHeadAttention(nn.Module):
         return ops.KVProjectFn.apply(k.reshape(-1, k.size(-1)), self.w_ks.weight, self.w_ks.bias,
                                      self.w_vs.weight, self.w_vs.bias)
 
-    def forward(self, q, k, v, mask=None, kv_proj=None):
+    def forward_rows(self, x2, B, segL, mask=None, kv_proj=None):
+        """Sub-layer on a ragged batch of rows: x2 (B*sum(segL), d_model); segment s holds B sequences of length
+        segL[s] (the SBL decoder batches the steps of one teacher-forced run this way).  kv_proj=None: self-attention
+        inside each segment; else cross-attention to the pre-projected [K|V] rows (B*Lk, 2*n_head*64).
+        mask: None | 'causal' (| a (B,Lq,Lk) tensor when there is a single segment).  Returns (out rows, attn flat)."""
         self._fuse()
-        sz_b, len_q, _ = q.size()
-        len_k = k.size(1)
         drop_p = self.dropout.p if self.training else 0.0
-        mask_kind, mask_t = _as_mask(mask, sz_b, len_q, len_k)
         ln = self.layer_norm
-        if kv_proj is None and q is k and k is v:
-            return ops.MHAFn.apply(q, None, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
-                                   self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, ln.weight, ln.bias,
-                                   self.n_head, mask_kind, mask_t, drop_p, ln.eps)
+        if isinstance(mask, str) or mask is None:
+            mask_kind, mask_t = (1, None) if mask == "causal" else (0, None)
+        else:
+            assert len(segL) == 1
+            Lk = segL[0] if kv_proj is None else kv_proj.size(0) // B
+            mask_kind, mask_t = _as_mask(mask, B, segL[0], Lk)
         if kv_proj is None:
+            return ops.MHAFn.apply(x2, None, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
+                                   self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, ln.weight, ln.bias,
+                                   self.n_head, mask_kind, mask_t, drop_p, ln.eps, B, tuple(segL))
+        return ops.MHAFn.apply(x2, kv_proj, self.w_qs.weight, self.w_qs.bias, None, None, None, None,
+                               self.fc.weight, self.fc.bias, ln.weight, ln.bias,
+                               self.n_head, mask_kind, mask_t, drop_p, ln.eps, B, tuple(segL))
+
+    def forward(self, q, k, v, mask=None, kv_proj=None):
+        sz_b, len_q, d = q.size()
+        len_k = k.size(1)
+        if kv_proj is None and not (q is k and k is v):
+            self._fuse()
             if k is v:
                 kv_proj = self.project_kv(k)
             else:
                 kk = ops.linear(k, self.w_ks.weight, self.w_ks.bias).reshape(-1, self.n_head * self.d_k)
                 vv = ops.linear(v, self.w_vs.weight, self.w_vs.bias).reshape(-1, self.n_head * self.d_v)
                 kv_proj = torch.cat([kk, vv], 1)
-        return ops.MHAFn.apply(q, kv_proj, self.w_qs.weight, self.w_qs.bias, None, None, None, None,
-                               self.fc.weight, self.fc.bias, ln.weight, ln.bias,
-                               self.n_head, mask_kind, mask_t, drop_p, ln.eps)
+        out, attn = self.forward_rows(q.reshape(sz_b * len_q, d), sz_b, (len_q,), mask=mask, kv_proj=kv_proj)
+        return out.view(sz_b, len_q, d), attn.view(self.n_head * sz_b, len_q, len_k)
 
 
 class ScaledDotProductAttention(nn.Module):

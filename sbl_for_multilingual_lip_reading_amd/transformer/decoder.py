@@ -21,9 +21,16 @@ class Decoder(nn.Module):
         once per step (step-invariant; exact algebra);
       * the aliased in-place fusion loops are one kernel, A' = A + flip(B), B' = 2B + flip(A);
       * tokens, argmax and the teacher-forcing select stay on the device (no host sync in the 16-step loop);
-        the coin itself is still `random.random() > 0.5`, one draw per step, so `random.seed(k)` reproduces the
-        reference's choices.  Set `self.coins_dev` to a device int32 tensor of 16 flags to take the coins from
-        device memory instead (hipGraph replay).
+      * the coins are still `random.random() > 0.5`, 16 draws in the reference's order (so `random.seed(k)`
+        reproduces its choices), but they are drawn up front: step i+1 depends on step i only when coin i says
+        "feed back the own argmax" (decoder.py:176-186).  A run of steps whose inputs are all teacher-forced is
+        therefore processed as ONE ragged batch (rows of all its prefixes concatenated; weights are shared by the
+        steps), which turns 16 sequential stages into 1 + (#own-argmax coins) ~ 8.5 on average.  The per-step
+        results are identical: every row-wise op is unchanged and attention / fusion / embedding work per segment.
+        `batch_teacher_runs = False` restores the one-stage-per-step schedule (also used by greedy inference,
+        where every coin is "own argmax").
+    Set `self.coins_dev` to a device int32[16] tensor to take the coins from device memory (one captured hipGraph
+    for every coin pattern; implies the per-step schedule), or `self.coins_host` to a list of 16 bools to fix them.
     '''
 
     def __init__(
@@ -67,9 +74,11 @@ class Decoder(nn.Module):
         self.tgt_word_prj_l2r = nn.Linear(512, 58, bias=False)
         self.tgt_word_prj_r2l = nn.Linear(512, 58, bias=False)
 
-        self.two_streams = True    # run the two directions' layers on two HIP streams (joined before each fusion)
-        self.coins_dev = None      # optional device int32[16]: 1 = feed own argmax (graph replay)
-        self.last_coins = None     # the coins of the last forward (host list), for inspection / parity tests
+        self.two_streams = True          # run the two directions' layers on two HIP streams (joined before each fusion)
+        self.batch_teacher_runs = True   # batch the steps of a teacher-forced run (see class docstring)
+        self.coins_dev = None            # optional device int32[16]: 1 = feed own argmax (graph replay, per-step schedule)
+        self.coins_host = None           # optional list of 16 bools overriding the python `random` draws
+        self.last_coins = None           # the coins of the last forward (host list), for inspection / parity tests
 
     def preprocess(self, padded_input):
         """Generate decoder input and output label from padded_input (decoder.py:62-77): strip IGNORE_ID,
@@ -98,7 +107,7 @@ class Decoder(nn.Module):
         return [first] + list(stack)
 
     def _run(self, encoder_outputs, gold_l2r, gold_r2l, teacher_mode):
-        """The 16-step loop shared by forward (decoder.py:106-186) and recognize_beam (:310-383)."""
+        """The 16 decoding steps shared by forward (decoder.py:106-186) and recognize_beam (:310-383)."""
         maxlen = config.MAX_DECODE_LEN
         N = encoder_outputs.size(0)
         dev = encoder_outputs.device
@@ -112,46 +121,77 @@ class Decoder(nn.Module):
         pe = self.positional_encoding.pe[0]
         heads = (self.tgt_word_prj_l2r.weight, self.tgt_word_prj_r2l.weight)
         golds = (gold_l2r, gold_r2l)
-        outs = ([], [])
-        coins = []
+        outs = ([None] * maxlen, [None] * maxlen)
+
+        # ---- coins (True = feed back the own argmax after that step)
+        dev_coins = teacher_mode and self.coins_dev is not None
+        if not teacher_mode:
+            coins = [True] * maxlen
+        elif dev_coins:
+            coins = None
+        elif self.coins_host is not None:
+            coins = [bool(c) for c in self.coins_host]
+        else:   # decoder.py:176, one draw per step, same order
+            coins = [random.random() > config.TEACHER_COIN_THRESHOLD for _ in range(maxlen)]
+        self.last_coins = coins
+
+        # ---- stages: maximal runs of steps whose input tokens are known when the run starts
+        if coins is None or not self.batch_teacher_runs:
+            stages = [(i, i) for i in range(maxlen)]
+        else:
+            stages, i = [], 0
+            while i < maxlen:
+                j = i
+                while j < maxlen - 1 and not coins[j]:
+                    j += 1
+                stages.append((i, j))
+                i = j + 1
+            for k in range(maxlen):              # teacher-forced tokens are known up front
+                if not coins[k]:
+                    for d in (0, 1):
+                        ops.argmax_select(None, golds[d], ys[d], k, 0)
+
         side = main = None
         if self.two_streams and dev.type == "cuda":
             main = torch.cuda.current_stream(dev)
             side = ops.side_stream(dev)
             ops.set_main_stream(main)
-        for i in range(maxlen):
-            L = i + 1
-            x = [ops.dropout(ops.EmbedPEFn.apply(ys[d], L, emb, pe), self.dropout.p, self.training) for d in (0, 1)]
+
+        ops.begin_defer()      # decoder weights are used once per stage: their dW GEMMs are deferred and merged
+        for (i0, i1) in stages:
+            segL = tuple(range(i0 + 1, i1 + 2))            # prefix lengths of the steps in this stage
+            x = [ops.dropout(ops.EmbedPEFn.apply(ys[d], N, segL, emb, pe), self.dropout.p, self.training) for d in (0, 1)]
             for n in range(self.n_layers):
                 slf_mask = 'causal' if n == 0 else None       # decoder.py:123-125 vs :150,:157
                 if side is None:
                     for d in (0, 1):
-                        x[d], _, _ = layers[d][n](x[d], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[d][n])
+                        x[d] = layers[d][n].forward_rows(x[d], N, segL, slf_mask, kv[d][n])
                 else:
                     # the l2r and r2l layers are independent until the fusion: run them on two HIP streams so their
                     # small kernels overlap on the 256 CUs (fork / join is captured as parallel hipGraph branches;
                     # autograd replays backward on the same two streams)
                     side.wait_stream(main)
-                    x[0], _, _ = layers[0][n](x[0], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[0][n])
+                    x[0] = layers[0][n].forward_rows(x[0], N, segL, slf_mask, kv[0][n])
                     with torch.cuda.stream(side):
-                        x[1], _, _ = layers[1][n](x[1], encoder_outputs, slf_attn_mask=slf_mask, enc_kv=kv[1][n])
+                        x[1] = layers[1][n].forward_rows(x[1], N, segL, slf_mask, kv[1][n])
                     main.wait_stream(side)
-                x[0], x[1] = ops.FusionFn.apply(x[0], x[1])
-            preds = [ops.linear(x[d][:, -1], heads[d]) for d in (0, 1)]
-            outs[0].append(preds[0])
-            outs[1].append(preds[1])
-            if teacher_mode:
-                if self.coins_dev is not None:
-                    own = 0
-                else:
-                    own = int(random.random() > config.TEACHER_COIN_THRESHOLD)   # decoder.py:176
-                    coins.append(bool(own))
-            else:
-                own = 1
+                x[0], x[1] = ops.FusionFn.apply(x[0], x[1], N, segL)
             for d in (0, 1):
-                ops.argmax_select(preds[d].detach(), golds[d], ys[d], i, own,
-                                  self.coins_dev if teacher_mode else None)
-        self.last_coins = coins
+                last = ops.GatherLastFn.apply(x[d], N, segL)           # (nseg*N, 512): position -1 of every prefix
+                pred = ops.linear(last, heads[d])                      # (nseg*N, 58)
+                for s, step in enumerate(range(i0, i1 + 1)):
+                    outs[d][step] = pred[s * N:(s + 1) * N]
+            # token fed to the next stage
+            if coins is None:
+                for d in (0, 1):
+                    ops.argmax_select(outs[d][i1].detach(), golds[d], ys[d], i1, 0, self.coins_dev)
+            elif coins[i1]:
+                for d in (0, 1):
+                    ops.argmax_select(outs[d][i1].detach(), golds[d], ys[d], i1, 1)
+            elif not self.batch_teacher_runs:
+                for d in (0, 1):
+                    ops.argmax_select(outs[d][i1].detach(), golds[d], ys[d], i1, 0)
+        ops.end_defer()
         return outs, ys
 
     def forward(self, padded_input_l2r, padded_input_r2l, encoder_outputs,
@@ -183,6 +223,13 @@ class DecoderLayer(nn.Module):
         self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def forward_rows(self, x2, B, segL, slf_attn_mask, enc_kv):
+        """The layer on a ragged batch of rows (see MultiHeadAttention.forward_rows); non_pad_mask is all ones on
+        this path (decoder.py:109,112)."""
+        x2, _ = self.slf_attn.forward_rows(x2, B, segL, mask=slf_attn_mask)
+        x2, _ = self.enc_attn.forward_rows(x2, B, segL, mask=None, kv_proj=enc_kv)
+        return self.pos_ffn(x2)
 
     def forward(self, dec_input, enc_output, non_pad_mask=None, slf_attn_mask=None, dec_enc_attn_mask=None,
                 enc_kv=None):

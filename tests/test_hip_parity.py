@@ -341,6 +341,77 @@ def test_decoder_layer_and_fusion_golden(ops, golden_modules):
         assert maxdiff(x2, aa + bb.flip(1)) < 1e-6 and maxdiff(y2, 2 * bb + aa.flip(1)) < 1e-6
 
 
+def test_ragged_run_kernels_match_per_step(ops, golden_modules):
+    """The segmented (one launch per teacher-forced run) kernels must reproduce the per-step launches exactly:
+    embedding, fusion, gather-last and a whole decoder layer (self causal/plain + cross attention + FFN), fwd+bwd."""
+    from sbl_for_multilingual_lip_reading_amd.transformer.decoder import DecoderLayer
+    B, D, segL = 3, 512, (2, 3, 4, 7)
+    R = B * sum(segL)
+    pe = torch.from_numpy(golden_modules["pe"]).to(DEV)
+    tok = torch.from_numpy(((detfill.uniform("rg.tok", (B, 17)) + 1) * 29).astype(np.int64).clip(0, 57)).to(DEV)
+    emb = U("rg.emb", (58, D)).to(DEV)
+    xs = ops.EmbedPEFn.apply(tok, B, segL, emb, pe)
+    off = 0
+    for L in segL:
+        assert maxdiff(xs[off:off + B * L].view(B, L, D), emb[tok[:, :L]] + pe[:L].unsqueeze(0)) == 0.0
+        off += B * L
+    a, b = U("rg.a", (R, D)).to(DEV), U("rg.b", (R, D)).to(DEV)
+    a2, b2 = ops.FusionFn.apply(a, b, B, segL)
+    last = ops.GatherLastFn.apply(a, B, segL)
+    off = 0
+    for s, L in enumerate(segL):
+        aa, bb = a[off:off + B * L].view(B, L, D), b[off:off + B * L].view(B, L, D)
+        assert maxdiff(a2[off:off + B * L].view(B, L, D), aa + bb.flip(1)) < 1e-6
+        assert maxdiff(b2[off:off + B * L].view(B, L, D), 2 * bb + aa.flip(1)) < 1e-6
+        assert maxdiff(last[s * B:(s + 1) * B], aa[:, -1]) == 0.0
+        off += B * L
+    dl = _load_det(DecoderLayer(512, 2048, 8, 64, 64, dropout=0.0)).to(DEV)
+    mem = U("rg.mem", (B, 29, 512)).to(DEV).requires_grad_(True)
+    for mask in ("causal", None):
+        x = U("rg.x", (R, D)).to(DEV).requires_grad_(True)
+        w = U("rg.w", (R, D)).to(DEV)
+        dl.zero_grad(); mem.grad = None
+        y = dl.forward_rows(x, B, segL, mask, dl.enc_attn.project_kv(mem))
+        (y * w).sum().backward()
+        g_run = {n: p.grad.clone() for n, p in dl.named_parameters()}
+        gx_run, gm_run = x.grad.clone(), mem.grad.clone()
+        dl.zero_grad(); mem.grad = None
+        x2 = x.detach().clone().requires_grad_(True)
+        off, ys_ = 0, []
+        kvp = dl.enc_attn.project_kv(mem)
+        for L in segL:
+            ys_.append(dl(x2[off:off + B * L].view(B, L, D), mem, slf_attn_mask=mask, enc_kv=kvp)[0].reshape(B * L, D))
+            off += B * L
+        y_ref = torch.cat(ys_, 0)
+        (y_ref * w).sum().backward()
+        assert maxdiff(y, y_ref) < 1e-6
+        assert maxdiff(gx_run, x2.grad) < 1e-5 and maxdiff(gm_run, mem.grad) < 2e-5
+        for n, p in dl.named_parameters():
+            assert maxdiff(g_run[n], p.grad) < 2e-5 * max(1.0, float(p.grad.abs().max())), n
+
+
+def test_batched_teacher_runs_equal_per_step_schedule(ops):
+    """Decoder.forward with the run-batched schedule == the one-stage-per-step schedule (same coins), fwd + grads."""
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    B, T, H, W, ne, nd = 3, 4, 24, 24, 1, 2
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 41)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    res = []
+    for batched in (True, False):
+        m = build_model(ne, nd).train()
+        m.decoder.batch_teacher_runs = batched
+        random.seed(13)
+        pl, gl, pr, gr = m(xd, ld, rd)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        res.append((pl.detach(), pr.detach(), loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()}, m.decoder.last_coins))
+    assert res[0][4] == res[1][4] and 0 < sum(res[0][4]) < 16
+    assert maxdiff(res[0][0], res[1][0]) < 2e-5 and maxdiff(res[0][1], res[1][1]) < 2e-5 and abs(res[0][2] - res[1][2]) < 1e-5
+    for n, g in res[0][3].items():
+        if n.startswith("decoder") or n.startswith("encoder"):
+            assert maxdiff(g, res[1][3][n]) < 1e-3 * float(res[1][3][n].abs().max()) + 2e-6, n
+
+
 def test_loss_golden(ops, golden_modules):
     from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance
     g = golden_modules
@@ -361,12 +432,12 @@ def test_embed_argmax_adam_rowscale(ops, golden_modules):
     emb = U("emb.w", (V, D)).to(DEV).requires_grad_(True)
     pe = torch.from_numpy(g["pe"]).to(DEV)
     for L in (1, 7, 16):
-        out = ops.EmbedPEFn.apply(tok, L, emb, pe)
+        out = ops.EmbedPEFn.apply(tok, B, (L,), emb, pe)
         ref = emb.detach()[tok[:, :L]] + pe[:L].unsqueeze(0)
-        assert maxdiff(out, ref) == 0.0
+        assert maxdiff(out.view(B, L, D), ref) == 0.0
     emb.grad = None
     w = U("emb.dy", (B, 16, D)).to(DEV)
-    (ops.EmbedPEFn.apply(tok, 16, emb, pe) * w).sum().backward()
+    (ops.EmbedPEFn.apply(tok, B, (16,), emb, pe).view(B, 16, D) * w).sum().backward()
     ref = torch.zeros(V, D, device=DEV).index_add_(0, tok[:, :16].reshape(-1), w.reshape(-1, D))
     assert maxdiff(emb.grad, ref) < 1e-5
     # argmax / select, incl. ties (first index wins)
