@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="clips in the one CPU-oracle step (32 ~ 7 s on 16 cores)")
     ap.add_argument("--coin-patterns", type=int, default=4, help="distinct teacher-forcing coin patterns (one graph each)")
     ap.add_argument("--per-step-decoder", action="store_true", help="one decoder stage per step (no run batching)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-stream", action="store_true", help="run the two decoder directions on one stream")
     ap.add_argument("--hang-dump", type=int, default=0, help="debug: dump all Python stacks after this many seconds")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
@@ -167,11 +168,16 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)          # one rank per GPU; wraps only in single-GPU rehearsals (gloo)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from sbl_for_multilingual_lip_reading_amd import _lib, detfill, dp, ops
     from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device

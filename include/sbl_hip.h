@@ -220,6 +220,16 @@ int sbl_smoothed_ce_fwd(const float* pred, const int64_t* gold, float* out3, int
 int sbl_smoothed_ce_bwd(const float* pred, const int64_t* gold, const float* out3, const float* gscale, float* dpred,
                         int R, int C, float eps, int ignore_id, sbl_stream_t stream);
 
+/* ---------------------------------------------------------------- device input pipeline
+ * uint8 grayscale frames (N,Tin,Hin,Win) -> fp32 clips (N,Tout,Hc,Wc): out = lut256[in[n, src_frame[n,t], y1[n]+y,
+ * x1[n] + (flip[n] ? Wc-1-x : x)]], zero where src_frame < 0.  lut256[v] = float32((v/255. - mean)/std) computed in
+ * double by the caller: bit-identical to SBL/data_gen.py:122-125 + cvtransforms.py:44-48 (ColorNormalize), :22-33 /
+ * :7-19 (Random/CenterCrop), :36-41 (HorizontalFlip), data_gen.py:104-108 (FrameRemoval as a source-frame map) and
+ * :290-296 (zero padding to 30 frames).  y1/x1/flip: device int32[N]; src_frame: device int32[N*Tout]. */
+int sbl_preprocess_clips(const uint8_t* in, float* out, const float* lut256, const int* y1, const int* x1, const int* flip,
+                         const int* src_frame, int N, int Tin, int Hin, int Win, int Tout, int Hc, int Wc,
+                         sbl_stream_t stream);
+
 /* ---------------------------------------------------------------- fused Adam
  * torch.optim.Adam(betas=(0.9,0.98), eps=1e-9) over a flat fp32 buffer, grad pre-scaled by
  * grad_scale (1/world_size): SBL/train.py:75, SBL/transformer/optimizer.py:18-27. */

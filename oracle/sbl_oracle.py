@@ -372,6 +372,29 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.98, eps=1e-9):
 
 
 # --------------------------------------------------------------------------- #
+# input pipeline: SBL/data_gen.py:122-125,104-108,276-296; SBL/cvtransforms.py:7-48  (numpy, like the reference)
+# The reference's cvtransforms.py imports cv2 (absent here), so these few lines are restated, not imported:
+# "parity unpinned" by a reference run; the arithmetic is ColorNormalize's one formula in float64.
+# --------------------------------------------------------------------------- #
+def preprocess_clip_ref(frames_u8, y1, x1, flip, removed, Tout=30, crop=(88, 88)):
+    """frames_u8: (Tin,Hin,Win) uint8.  removed: iterable of frame indices i>0 that FrameRemoval replaces by frame
+    i-1 (sequentially, data_gen.py:104-108).  Returns float32 (Tout, th, tw)."""
+    import numpy as np
+    vid = frames_u8.astype(np.float64) / 255.                      # load_file
+    vid = (vid - 0.413621) / 0.1700239                             # ColorNormalize
+    th, tw = crop
+    vid = vid[:, y1:y1 + th, x1:x1 + tw].copy()                    # RandomCrop / CenterCrop
+    if flip:
+        vid = vid[:, :, ::-1].copy()                               # HorizontalFlip (cv2.flip(img, 1))
+    for i in range(vid.shape[0]):                                  # FrameRemoval
+        if i in removed and i > 0:
+            vid[i] = vid[i - 1]
+    out = np.zeros((Tout, th, tw), dtype=np.float32)               # vids[:length] = vid
+    out[:vid.shape[0]] = vid
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # helpers used by tests / bench
 # --------------------------------------------------------------------------- #
 def state_dict_shapes(n_layers_enc=6, n_layers_dec=6, d_input=512, d_model=512, d_inner=2048,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sbl_smoothed_ce_fwd": [P, P, P, I, I, F, I, P],
     "sbl_smoothed_ce_bwd": [P, P, P, P, P, I, I, F, I, P],
     "sbl_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
+    "sbl_preprocess_clips": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
 }
 
 _lib = None

@@ -345,3 +345,45 @@ extern "C" int sbl_rowscale(const float* x, const float* s, float* y, long M, in
     SBL_LAUNCH_CHECK("sbl_rowscale");
     return 0;
 }
+
+// ------------------------------------------------------------------ device input pipeline
+// uint8 grayscale frames -> the fp32 clips the stem reads: /255, ColorNormalize, crop, per-clip horizontal flip
+// (cvtransforms.py:7-48), frame removal + zero padding to Tout frames (data_gen.py:104-108, 290-296) expressed as a
+// source-frame map (-1 = zero frame).  The 256 possible pixel values go through a LUT computed in double on the
+// host, so the result is bit-identical to the reference's float64 numpy arithmetic cast to float32.
+__global__ __launch_bounds__(256) void preprocess_clips_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                               const float* __restrict__ lut, const int* __restrict__ y1,
+                                                               const int* __restrict__ x1, const int* __restrict__ flip,
+                                                               const int* __restrict__ src_frame, int N, int Tin, int Hin,
+                                                               int Win, int Tout, int Hc, int Wc) {
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const long total = (long)N * Tout * Hc * Wc;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % Wc);
+        long r = i / Wc;
+        const int y = (int)(r % Hc);
+        r /= Hc;
+        const int t = (int)(r % Tout);
+        const int n = (int)(r / Tout);
+        const int st = src_frame[n * Tout + t];
+        float v = 0.f;
+        if (st >= 0) {
+            const int sx = x1[n] + (flip[n] ? (Wc - 1 - x) : x);
+            v = s_lut[in[(((long)n * Tin + st) * Hin + (y1[n] + y)) * Win + sx]];
+        }
+        out[i] = v;
+    }
+}
+extern "C" int sbl_preprocess_clips(const uint8_t* in, float* out, const float* lut256, const int* y1, const int* x1,
+                                    const int* flip, const int* src_frame, int N, int Tin, int Hin, int Win, int Tout, int Hc,
+                                    int Wc, sbl_stream_t stream) {
+    SBL_REQUIRE(in && out && lut256 && y1 && x1 && flip && src_frame, "sbl_preprocess_clips: null pointer");
+    SBL_REQUIRE(N > 0 && Tin > 0 && Tout > 0 && Hc > 0 && Wc > 0 && Hc <= Hin && Wc <= Win, "sbl_preprocess_clips: bad dims");
+    const long total = (long)N * Tout * Hc * Wc;
+    hipLaunchKernelGGL(preprocess_clips_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, in, out, lut256, y1, x1,
+                       flip, src_frame, N, Tin, Hin, Win, Tout, Hc, Wc);
+    SBL_LAUNCH_CHECK("sbl_preprocess_clips");
+    return 0;
+}

@@ -988,3 +988,24 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     """Fused Adam over flat fp32 buffers (SBL/train.py:75; optimizer.py:18-27)."""
     _need_cuda(p, g, m, v)
     call("sbl_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _s())
+
+
+_LUT = {}
+
+
+def preprocess_clips(frames_u8, y1, x1, flip, src_frame, Tout=30, crop=(88, 88), mean=0.413621, std=0.1700239):
+    """Device input pipeline (SBL/data_gen.py:276-296 + cvtransforms.py): uint8 (N,Tin,Hin,Win) grayscale frames ->
+    normalised, cropped, flipped, frame-mapped, zero-padded fp32 clips (N,Tout,Hc,Wc) in one kernel.  y1/x1/flip:
+    int32 (N,) device tensors; src_frame: int32 (N,Tout), -1 = zero frame."""
+    import numpy as np
+    _need_cuda(frames_u8, y1, x1, flip, src_frame)
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    N, Tin, Hin, Win = frames_u8.shape
+    key = (frames_u8.device.index, mean, std)
+    lut = _LUT.get(key)
+    if lut is None:   # float32((v/255. - mean)/std) in double, exactly the reference's numpy arithmetic
+        lut = _LUT[key] = torch.from_numpy(((np.arange(256, dtype=np.float64) / 255. - mean) / std).astype(np.float32)).to(frames_u8.device)
+    out = torch.empty(N, Tout, crop[0], crop[1], device=frames_u8.device, dtype=torch.float32)
+    call("sbl_preprocess_clips", _p(frames_u8), _p(out), _p(lut), _p(y1.contiguous()), _p(x1.contiguous()), _p(flip.contiguous()),
+         _p(src_frame.contiguous()), N, Tin, Hin, Win, Tout, crop[0], crop[1], _s())
+    return out

@@ -27,3 +27,41 @@ class TransformerOptimizer(object):
                                               self.step_num * (self.warmup_steps ** (-1.5)))
         for param_group in self.optimizer.param_groups:
             param_group['lr'] = self.lr
+
+
+class FusedAdam(object):
+    """torch.optim.Adam(betas=(0.9, 0.98), eps=1e-9) as SBL/train.py:75 configures it, as ONE kernel launch over the
+    flat parameter / gradient buffers of a dp.FlatModel (81 M parameters: 2.3 GB of traffic per step instead of 475
+    per-tensor launches).  Duck-types the slice of the torch optimizer API that TransformerOptimizer and the
+    reference's train loop use: param_groups[...]['lr'], zero_grad(), step(), state_dict()/load_state_dict().
+    grad_scale folds the 1/world_size of data-parallel averaging into the update when the exchange sums."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, grad_scale=1.0):
+        import torch
+        from ._env import ops
+        self._ops = ops
+        self.flat = flat
+        self.param_groups = [{"params": list(flat.model.parameters()), "lr": lr, "betas": betas, "eps": eps}]
+        self.exp_avg = torch.zeros_like(flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat.flat_param)
+        self.step_count = 0
+        self.grad_scale = grad_scale
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.step_count += 1
+        self._ops.adam_step(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, g["lr"],
+                            g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = sd["lr"]

@@ -633,6 +633,67 @@ def test_flat_direct_accumulation_and_two_streams_match_plain_autograd(ops):
     assert relerr(flat.flat_grad[a:b], 2 * first[a:b]) < 1e-3
 
 
+def test_device_input_pipeline_bit_exact(ops):
+    """uint8 frames -> normalised / cropped / flipped / frame-removed / zero-padded clips, bit-identical to the numpy
+    restatement of SBL/data_gen.py + cvtransforms.py (the reference's file needs cv2, absent here)."""
+    from oracle import sbl_oracle as O
+    rng = np.random.RandomState(5)
+    N, Tin, Hin, Win = 5, 29, 96, 96
+    frames = rng.randint(0, 256, size=(N, Tin, Hin, Win)).astype(np.uint8)
+    y1, x1 = rng.randint(0, 9, size=N), rng.randint(0, 9, size=N)
+    flip = rng.rand(N) > 0.5
+    lens = [29, 29, 17, 29, 5]
+    removed = [set(int(i) for i in np.nonzero(rng.rand(l) < 0.2)[0]) for l in lens]
+    src = np.full((N, 30), -1, dtype=np.int32)
+    ref = np.zeros((N, 30, 88, 88), dtype=np.float32)
+    for n in range(N):
+        cur = list(range(lens[n]))
+        for i in range(1, lens[n]):
+            if i in removed[n]:
+                cur[i] = cur[i - 1]
+        src[n, :lens[n]] = cur
+        ref[n] = O.preprocess_clip_ref(frames[n, :lens[n]], int(y1[n]), int(x1[n]), bool(flip[n]), removed[n])
+    out = ops.preprocess_clips(torch.from_numpy(frames).to(DEV), torch.from_numpy(y1.astype(np.int32)).to(DEV),
+                               torch.from_numpy(x1.astype(np.int32)).to(DEV), torch.from_numpy(flip.astype(np.int32)).to(DEV),
+                               torch.from_numpy(src).to(DEV))
+    assert out.shape == (N, 30, 88, 88) and np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_fused_adam_training_steps_match_torch_adam(ops):
+    """Three optimizer steps (fwd + bwd + Noam-scheduled Adam, SBL/train.py:188-199) with the fused flat Adam ==
+    the same steps with torch.optim.Adam on an identically initialised HIP model."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    from sbl_for_multilingual_lip_reading_amd.transformer.optimizer import FusedAdam, TransformerOptimizer
+    B, T, H, W, ne, nd = 2, 4, 24, 24, 1, 1
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 51)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    m1, m2 = build_model(ne, nd).train(), build_model(ne, nd).train()
+    opt1 = TransformerOptimizer(torch.optim.Adam(m1.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-09), warmup_steps=2, k=0.5)
+    flat = dp.FlatModel(m2)
+    opt2 = TransformerOptimizer(FusedAdam(flat, betas=(0.9, 0.98), eps=1e-09), warmup_steps=2, k=0.5)
+    losses = ([], [])
+    for step in range(3):
+        for i, (m, opt) in enumerate(((m1, opt1), (m2, opt2))):
+            random.seed(100 + step)
+            opt.zero_grad()
+            pl, gl, pr, gr = m(xd, ld, rd)
+            loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+            loss.backward()
+            opt.step()
+            losses[i].append(loss.item())
+        assert abs(opt1.lr - opt2.lr) < 1e-12
+    assert max(abs(a - b) for a, b in zip(*losses)) < 2e-3 and losses[0][2] != losses[0][0]
+    p1 = dict(m1.named_parameters())
+    # Adam's first steps move every element by ~lr*sign(g): elements whose gradient is rounding noise (e.g. the
+    # analytically-zero K-bias gradients, BN-amplified frontend noise) can take the opposite sign in the two
+    # summation orders, so compare the matrices of the transformer in relative L2, not element-wise
+    for n, p in m2.named_parameters():
+        if (n.startswith("decoder") or n.startswith("encoder")) and p.dim() >= 2:
+            num = float((p - p1[n]).norm())
+            assert num < 2e-3 * float(p1[n].norm()) + 1e-6, (n, num)
+
+
 @pytest.mark.parametrize("tag", ["small", "full"])
 def test_recognize_golden(ops, tag):
     g = load_golden("recognize_%s.npz" % tag)
