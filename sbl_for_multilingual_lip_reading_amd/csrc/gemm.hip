@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include "mfma_gemm.h"
 #include "skinny_gemm.h"
 
@@ -101,7 +102,8 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
     if (!transA || transB) vec = vec && (K % 4 == 0);
     const bool plain = !bias && !relu && !relu_mask;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    const bool big = (M >= 1024 && N >= 256 && tiles64 >= 2048);
+    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 2048;   // tuning knob
+    const bool big = (M >= 1024 && N >= 256 && tiles64 >= big_min);
     // split K when the output has too few 64x64 tiles to fill 256 CUs: aim at ~256 workgroups, chunks of at
     // least one 64-deep macro step, at most 8 slices (the last-arriving workgroup reads every slab)
     int splits = 1;
@@ -172,31 +174,48 @@ extern "C" int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda,
     hipStream_t s = (hipStream_t)stream;
     SBL_REQUIRE(nseg >= 1 && nseg <= SBL_MAX_KSEG && A_ptrs && B_ptrs && seg_rows && C, "sbl_wgrad_seg_f32: bad segment list (nseg=%d)", nseg);
     SBL_REQUIRE(M > 0 && N > 0 && lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0, "sbl_wgrad_seg_f32: bad dims M=%d N=%d lda=%ld ldb=%ld", M, N, lda, ldb);
-    SegMC<64> al, bl;
+    static const int seg_tile_env = getenv("SBL_SEG_TILE") ? atoi(getenv("SBL_SEG_TILE")) : 0;       // tuning knobs
+    static const int seg_ku = getenv("SBL_SEG_KU") ? atoi(getenv("SBL_SEG_KU")) : 2;
+    static const int seg_target = getenv("SBL_SEG_TARGET") ? atoi(getenv("SBL_SEG_TARGET")) : 768;
     long K = 0;
-    for (int t = 0; t < SBL_MAX_KSEG; ++t) {
-        al.kcum[t] = bl.kcum[t] = (int)K;
-        if (t < nseg) {
-            SBL_REQUIRE(A_ptrs[t] && B_ptrs[t] && seg_rows[t] > 0 && sbl_aligned16(A_ptrs[t]) && sbl_aligned16(B_ptrs[t]), "sbl_wgrad_seg_f32: segment %d null/unaligned/empty", t);
-            al.p[t] = A_ptrs[t];
-            bl.p[t] = B_ptrs[t];
-            K += seg_rows[t];
-        } else {
-            al.p[t] = bl.p[t] = nullptr;
-        }
+    bool aligned = true;
+    for (int t = 0; t < nseg; ++t) {
+        aligned = aligned && (seg_rows[t] % SBL_BK == 0);
+        SBL_REQUIRE(A_ptrs[t] && B_ptrs[t] && seg_rows[t] > 0 && sbl_aligned16(A_ptrs[t]) && sbl_aligned16(B_ptrs[t]), "sbl_wgrad_seg_f32: segment %d null/unaligned/empty", t);
+        K += seg_rows[t];
     }
     SBL_REQUIRE(K < (1L << 30), "sbl_wgrad_seg_f32: too many rows");
-    al.kcum[SBL_MAX_KSEG] = bl.kcum[SBL_MAX_KSEG] = (int)K;
-    al.nseg = bl.nseg = nseg;
-    al.ld = lda; bl.ld = ldb;
-    al.rows = M; bl.rows = N;
-    const long tiles = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    int splits = (int)((768 + tiles - 1) / tiles);          // ~3 workgroups per CU; chunks >= 128 rows
-    if (splits > K / 128) splits = (int)(K / 128);
-    if (splits < 1) splits = 1;
-    EpiStore<2, false> e{C, ldc, nullptr, 0, nullptr, nullptr, 0};
-    SplitCtl sc{nullptr, nullptr, a_colsum, sbl_next_stamp_slot(SBL_KID_TILED64)};
-    sbl_launch_gemm<SegMC<64>, SegMC<64>, EpiStore<2, false>, 64, 64, 2>(al, bl, e, M, N, (int)K, splits, s, sc);
+    unsigned long long* stamp = sbl_next_stamp_slot(SBL_KID_TILED64);
+    auto go = [&](auto al, auto tile_c, auto ku_c) {
+        constexpr int T = decltype(tile_c)::value, KUc = decltype(ku_c)::value;
+        decltype(al) bl;
+        long kc = 0;
+        for (int t = 0; t < SBL_MAX_KSEG; ++t) {
+            al.kcum[t] = bl.kcum[t] = (int)kc;
+            al.p[t] = t < nseg ? A_ptrs[t] : nullptr;
+            bl.p[t] = t < nseg ? B_ptrs[t] : nullptr;
+            if (t < nseg) kc += seg_rows[t];
+        }
+        al.kcum[SBL_MAX_KSEG] = bl.kcum[SBL_MAX_KSEG] = (int)K;
+        al.nseg = bl.nseg = nseg;
+        al.ld = lda; bl.ld = ldb;
+        al.rows = M; bl.rows = N;
+        const long tiles = (long)sbl_cdiv(M, T) * sbl_cdiv(N, T);
+        int splits = (int)((seg_target + tiles - 1) / tiles);          // ~3 workgroups per CU; chunks >= 128 rows
+        if (splits > K / 128) splits = (int)(K / 128);
+        if (splits < 1) splits = 1;
+        EpiStore<2, false> e{C, ldc, nullptr, 0, nullptr, nullptr, 0};
+        SplitCtl sc{nullptr, nullptr, a_colsum, stamp};
+        sbl_launch_gemm<decltype(al), decltype(al), EpiStore<2, false>, T, T, KUc>(al, bl, e, M, N, (int)K, splits, s, sc);
+    };
+    using std::integral_constant;
+    // 128x128 tiles (twice the flops per staged byte) once the weight has enough of them to split K over; measured at
+    // K = 4352 rows: 2048x512 67 vs 52 TF, 1536x512 58 vs 50, 512x512 26 vs 34 (tools/bench_gemm2.py)
+    const int seg_tile = seg_tile_env ? seg_tile_env : ((long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128) >= 48 ? 128 : 64);
+    if (!aligned) go(SegMC<64, false>{}, integral_constant<int, 64>{}, integral_constant<int, 2>{});
+    else if (seg_tile == 128) go(SegMC<128, true>{}, integral_constant<int, 128>{}, integral_constant<int, 1>{});
+    else if (seg_ku == 4) go(SegMC<64, true>{}, integral_constant<int, 64>{}, integral_constant<int, 4>{});
+    else go(SegMC<64, true>{}, integral_constant<int, 64>{}, integral_constant<int, 2>{});
     SBL_LAUNCH_CHECK("sbl_wgrad_seg_f32");
     return 0;
 }

@@ -137,7 +137,9 @@ struct DenseMC {
 // kcum[s])*ld + r] with s the segment containing k.  Lets one weight-gradient GEMM contract over all decoder
 // stages of a step (K ~ 4352 rows) instead of one skinny GEMM per stage.
 #define SBL_MAX_KSEG 16
-template <int BR>
+// ALIGNED: every segment length is a multiple of SBL_BK, so a BK-deep slice lies in one segment and the segment
+// lookup is workgroup-uniform (scalar unit) instead of 15 compare/select pairs per lane per load.
+template <int BR, bool ALIGNED = false>
 struct SegMC {
     static constexpr bool kColSum = true;
     const float* p[SBL_MAX_KSEG];
@@ -164,10 +166,11 @@ struct SegMC {
             const int k = k0 + s.kr + ps * RPP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < kend) {
+                const int kl = ALIGNED ? k0 : k;      // k0 is uniform: the lookup below then runs on the scalar unit
                 int sg = 0;
 #pragma unroll
                 for (int t = 1; t < SBL_MAX_KSEG; ++t)
-                    if (t < nseg && k >= kcum[t]) sg = t;
+                    if (t < nseg && kl >= kcum[t]) sg = t;
                 const float* q = p[sg] + (long)(k - kcum[sg]) * ld + s.c;
                 if (s.c + 3 < rows) {
                     v = *reinterpret_cast<const float4*>(q);
@@ -453,18 +456,31 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
                 bl.load(sb, k0 + MK + u * SBL_BK, kend, rb[u]);
             }
         }
+        // fragment ring: the LDS reads of k-pair ks+PD-1 are issued before the MFMAs of k-pair ks, so a wave that is
+        // alone on its SIMD still overlaps LDS latency with its own MFMAs (counted lgkmcnt instead of lgkmcnt(0))
+        constexpr int PD = (TM * TN >= 4) ? 2 : 4;
+        float a[PD][TM], b[PD][TN];
+#pragma unroll
+        for (int q = 0; q < PD - 1; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[q][i] = As[cur][2 * q + kh][arow + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[q][j] = Bs[cur][2 * q + kh][brow + j * 32];
+        }
 #pragma unroll
         for (int ks = 0; ks < MK / 2; ++ks) {
-            float a[TM], b[TN];
+            if (ks + PD - 1 < MK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][2 * ks + kh][arow + i * 32];
+                for (int i = 0; i < TM; ++i) a[(ks + PD - 1) % PD][i] = As[cur][2 * (ks + PD - 1) + kh][arow + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][2 * ks + kh][brow + j * 32];
+                for (int j = 0; j < TN; ++j) b[(ks + PD - 1) % PD][j] = Bs[cur][2 * (ks + PD - 1) + kh][brow + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks % PD][i], b[ks % PD][j], acc[i][j], 0, 0, 0);
         }
         if (has_next) {
 #pragma unroll

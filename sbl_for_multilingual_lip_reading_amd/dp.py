@@ -88,6 +88,11 @@ class FlatModel:
         return self.flat_grad[a:b]
 
 
+def _ops():
+    from . import ops
+    return ops
+
+
 class GradientExchange:
     """Averages the flat gradient over ranks: one RCCL all-reduce per segment on a side stream, launched from
     a hook that fires when the first parameter of the NEXT segment receives its gradient (i.e. the previous
@@ -129,7 +134,13 @@ class GradientExchange:
             return
         g = self.flat.segment_grad(seg)
         if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            if seg == "decoder.":
+                _ops().flush_deferred()       # the decoder's merged weight-gradient GEMMs must be issued first
+            side = _ops()._side_streams.get(cur.device_index)
+            if side is not None:
+                self.stream.wait_stream(side)
+            self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 g.mul_(1.0 / self.world)
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)

@@ -116,6 +116,16 @@ def _xs_out(*ts):
                     t.record_stream(main)
 
 
+def _side_to_main():
+    """Explicit fence when a side-stream tape node hands its result to the main stream (belt and braces next to the
+    autograd engine's own producer/consumer event)."""
+    cur = torch.cuda.current_stream()
+    if _side_streams.get(cur.device_index) is not None and cur == _side_streams[cur.device_index]:
+        main = _main_streams.get(cur.device_index)
+        if main is not None:
+            main.wait_stream(cur)
+
+
 _aux_streams = {}
 # Off by default: with the decoder's second stream also forking an auxiliary stream, hipStreamEndCapture /
 # instantiate segfaults on ROCm 7.2 (main+aux and main+side capture fine; main+side+aux does not), and
@@ -143,6 +153,7 @@ class WgradCollector:
     def __init__(self):
         self.entries = {}
         self.armed = False
+        self.flushes = 0
 
     def add(self, C, ldc, colsum, A, lda, B, ldb, rows, M, N):
         e = self.entries.get(C.data_ptr())
@@ -154,27 +165,61 @@ class WgradCollector:
         e["rows"].append(rows)
         if not self.armed:
             self.armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            _armed.append(self)
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
 
     def flush(self):
+        """Issue the collected GEMMs.  Called from a hook on the decoder's encoder_outputs gradient (every decoder
+        tape node has run by then: they all outrank the hoisted K/V projections in the engine's ready queue), so
+        the GEMMs go to the side stream and overlap the encoder / frontend backward on the main stream; called
+        again from the engine's end-of-backward callback, which issues anything that arrived late and joins."""
+        if not self.entries:
+            return
         cur = torch.cuda.current_stream()
         side = _side_streams.get(cur.device_index)
-        if side is not None:
+        run = cur
+        if side is not None and cur != side:
             cur.wait_stream(side)              # operands produced by the other direction's stream
-        for e in self.entries.values():
-            n = len(e["rows"])
-            for i in range(0, n, 16):
-                A, B, rows = e["A"][i:i + 16], e["B"][i:i + 16], e["rows"][i:i + 16]
-                k = len(rows)
-                pa = (_ct.c_void_p * k)(*[t.data_ptr() for t in A])
-                pb = (_ct.c_void_p * k)(*[t.data_ptr() for t in B])
-                pr = (_ct.c_int * k)(*rows)
-                call("sbl_wgrad_seg_f32", k, pa, e["lda"], pb, e["ldb"], pr, e["M"], e["N"], _p(e["C"]), e["ldc"],
-                     _p(e["colsum"]), _s())
-            for t in e["A"] + e["B"]:
-                t.record_stream(cur)
+            if FLUSH_ON_SIDE:
+                side.wait_stream(cur)
+                run = side
+        with torch.cuda.stream(run):
+            for e in self.entries.values():
+                n = len(e["rows"])
+                for i in range(0, n, 16):
+                    A, B, rows = e["A"][i:i + 16], e["B"][i:i + 16], e["rows"][i:i + 16]
+                    k = len(rows)
+                    pa = (_ct.c_void_p * k)(*[t.data_ptr() for t in A])
+                    pb = (_ct.c_void_p * k)(*[t.data_ptr() for t in B])
+                    pr = (_ct.c_int * k)(*rows)
+                    call("sbl_wgrad_seg_f32", k, pa, e["lda"], pb, e["ldb"], pr, e["M"], e["N"], _p(e["C"]), e["ldc"],
+                         _p(e["colsum"]), _s())
+                for t in e["A"] + e["B"]:
+                    t.record_stream(run)
         self.entries = {}
+        self.flushes += 1
+
+    def finish(self):
+        """Engine end-of-backward callback: late entries, then the main stream waits for the side stream."""
+        self.flush()
+        cur = torch.cuda.current_stream()
+        side = _side_streams.get(cur.device_index)
+        if side is not None and cur != side:
+            cur.wait_stream(side)
         self.armed = False
+        if self in _armed:
+            _armed.remove(self)
+
+
+FLUSH_ON_SIDE = os.environ.get("SBL_FLUSH_ON_SIDE", "1") != "0"
+_armed = []
+
+
+def flush_deferred():
+    """Issue every deferred weight-gradient GEMM collected so far (idempotent).  dp.GradientExchange calls this
+    before it all-reduces the decoder segment; the decoder calls it from its encoder_outputs gradient hook."""
+    for c in list(_armed):
+        c.flush()
 
 
 DEFER_WGRAD = os.environ.get("SBL_DEFER_WGRAD", "1") != "0"
@@ -526,14 +571,18 @@ class KVProjectFn(torch.autograd.Function):
     def backward(ctx, dkv):
         x2, wk, wv = ctx.saved_tensors
         dkv = dkv.contiguous()
+        _xs_in(dkv, x2)
         M, ldx = _rows(x2)
         N2, K = 2 * wk.size(0), wk.size(1)
         dev = dkv.device
         dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+        _xs_out(dx)
         gemm(0, 0, M, K, N2, dkv, N2, wk, K, dx, K)
         dw, acc, dw_ret = _target(ctx.gb[0], (N2, K), dev)
         db, _, db_ret = _target(ctx.gb[1], (N2,), dev, zero=True)
         wgrad_gemm(N2, K, M, dkv, N2, x2, ldx, dw, K, acc, db)
+        _xs_out(dw_ret, db_ret)
+        _side_to_main()     # dx joins the other direction's dx in the encoder-output gradient on the main stream
         h = N2 // 2
         if dw_ret is None:
             return dx, None, None, None, None

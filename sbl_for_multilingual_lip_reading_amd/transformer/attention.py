@@ -54,6 +54,8 @@ class MultiHeadAttention(nn.Module):
         with torch.no_grad():
             fw = torch.cat([w.data for w in ws], 0).contiguous()
             fb = torch.cat([b.data for b in bs], 0).contiguous()
+            if fw.is_cuda:      # one-time set-up: the old storages are released below, so the copies must have run
+                torch.cuda.current_stream(fw.device).synchronize()
             r = 0
             for w, b in zip(ws, bs):
                 n = w.size(0)

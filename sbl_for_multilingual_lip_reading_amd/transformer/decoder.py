@@ -112,8 +112,25 @@ class Decoder(nn.Module):
         N = encoder_outputs.size(0)
         dev = encoder_outputs.device
         layers = (self._layers(0), self._layers(1))
-        # hoisted cross-attention K/V (one GEMM per layer per direction per forward)
-        kv = [[lay.enc_attn.project_kv(encoder_outputs) for lay in layers[d]] for d in (0, 1)]
+        for d in (0, 1):            # parameter fusing (first call only) happens here, on the caller's stream
+            for lay in layers[d]:
+                lay.slf_attn._fuse()
+                lay.enc_attn._fuse()
+        side = main = None
+        if self.two_streams and dev.type == "cuda":
+            main = torch.cuda.current_stream(dev)
+            side = ops.side_stream(dev)
+            ops.set_main_stream(main)
+        # hoisted cross-attention K/V (one GEMM per layer per direction per forward).  The r2l projections are made on
+        # the side stream: autograd accumulates the per-stage K/V gradients on the stream of the node that consumes
+        # them, so a main-stream node here would make every main-stream backward step wait for the side stream.
+        kv = [[lay.enc_attn.project_kv(encoder_outputs) for lay in layers[0]], None]
+        if side is None:
+            kv[1] = [lay.enc_attn.project_kv(encoder_outputs) for lay in layers[1]]
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                kv[1] = [lay.enc_attn.project_kv(encoder_outputs) for lay in layers[1]]
         ys = [torch.full((N, maxlen + 1), self.eos_id, dtype=torch.long, device=dev) for _ in (0, 1)]
         for y in ys:
             y[:, 0] = self.sos_id
@@ -151,13 +168,11 @@ class Decoder(nn.Module):
                     for d in (0, 1):
                         ops.argmax_select(None, golds[d], ys[d], k, 0)
 
-        side = main = None
-        if self.two_streams and dev.type == "cuda":
-            main = torch.cuda.current_stream(dev)
-            side = ops.side_stream(dev)
-            ops.set_main_stream(main)
-
         ops.begin_defer()      # decoder weights are used once per stage: their dW GEMMs are deferred and merged
+        if encoder_outputs.requires_grad and torch.is_grad_enabled():
+            # d(loss)/d(encoder_outputs) is complete only after every decoder tape node has run: issue the merged
+            # weight-gradient GEMMs then (side stream), under the encoder / frontend backward
+            encoder_outputs.register_hook(lambda g: ops.flush_deferred())
         for (i0, i1) in stages:
             segL = tuple(range(i0 + 1, i1 + 2))            # prefix lengths of the steps in this stage
             x = [ops.dropout(ops.EmbedPEFn.apply(ys[d], N, segL, emb, pe), self.dropout.p, self.training) for d in (0, 1)]
