@@ -213,6 +213,350 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------ decoder-sized problems: one wavefront each
+// Lq <= 16 target tokens, Lk <= 32 keys (self-attention over a prefix, or cross-attention to 29 frames): the
+// (b, head, segment) problem is so small that a 256-thread workgroup spends its time in barriers and padding.
+// Here one wavefront owns one problem, operands go global -> registers -> v_mfma_f32_16x16x4_f32 (exact fp32,
+// same rate as 32x32x2) with no LDS and no barrier.  Lane l = (n = l & 15, g = l >> 4).  The MFMA contraction
+// slot kk = g may stand for any index as long as A and B agree, and so may the output column n, which lets every
+// operand be fetched with 16-byte loads:
+//   row fragment of X (16 rows x 64): lane (n, g) holds X[n][16c + 4g + e], c, e = 0..3  (4 float4 loads)
+//   S^T tile t (keys 16t..16t+15) = K_t Q^T  ->  lane (n, g) reg r = S[i = n][j = 16t + 4g + r]      ("T layout")
+//   S   tile t                    = Q K_t^T  ->  lane (n, g) reg r = S[i = 4g + r][j = 16t + n]      ("N layout")
+//   a T-layout matrix is an A operand for contractions over keys j (P V, dS K) with B = M[j][4n + e] (float4),
+//   an N-layout matrix (rows = keys on n after the operand swap) for contractions over queries i (P^T dO, dS^T Q).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct RowFrag {
+    float v[4][4];
+};
+__device__ __forceinline__ void frag_load(RowFrag& f, const float* __restrict__ base, long ld, int row, bool ok, int g) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) t = *reinterpret_cast<const float4*>(base + (long)row * ld + 16 * c + 4 * g);
+        f.v[c][0] = t.x; f.v[c][1] = t.y; f.v[c][2] = t.z; f.v[c][3] = t.w;
+    }
+}
+// D = A_frag(rows on n) * B_frag(rows on n)^T over the 64-wide head dim: D[4g + r][n] = sum_d A[4g + r][d] B[n][d]
+__device__ __forceinline__ f32x4 frag_dot(const RowFrag& a, const RowFrag& b) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = MFMA16(a.v[c][e], b.v[c][e], acc);
+    return acc;
+}
+__device__ __forceinline__ void ld4(float* dst, const float* __restrict__ src, bool ok) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) t = *reinterpret_cast<const float4*>(src);
+    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+}
+__device__ __forceinline__ float grp_sum_hi(float v) {   // across g (lanes n, n+16, n+32, n+48)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float grp_max_hi(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float grp_sum_lo(float v) {   // across n inside a 16-lane group
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct SmallProb {
+    int Lq, Lk, b, h;
+    long qrow, krow, pbase;
+};
+__device__ __forceinline__ SmallProb small_prob(int prob, int B, int H, const SegDesc& segs, int Lk_fixed) {
+    SmallProb P;
+    const int sidx = prob / (B * H);
+    P.b = (prob / H) % B;
+    P.h = prob % H;
+    int Lq = segs.L[0], ro = segs.row_off[0], po = segs.p_off[0];
+#pragma unroll
+    for (int t = 1; t < SBL_MAX_SEG; ++t)
+        if (t == sidx) { Lq = segs.L[t]; ro = segs.row_off[t]; po = segs.p_off[t]; }
+    P.Lq = Lq;
+    P.Lk = Lk_fixed > 0 ? Lk_fixed : Lq;
+    P.qrow = ro + (long)P.b * Lq;
+    P.krow = Lk_fixed > 0 ? (long)P.b * P.Lk : P.qrow;
+    P.pbase = po + ((long)P.h * B + P.b) * Lq * P.Lk;
+    return P;
+}
+
+__global__ __launch_bounds__(256) void attention_small_fwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ k,
+                                                                  long ldk, const float* __restrict__ v, long ldv,
+                                                                  float* __restrict__ o, long ldo, float* __restrict__ p_out,
+                                                                  int causal, int B, int H, SegDesc segs, int Lk_fixed,
+                                                                  float scale, uint32_t thresh, float keep_scale,
+                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int prob = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (prob >= nprob) return;   // whole wavefront; the kernel has no barrier
+    const SmallProb P = small_prob(prob, B, H, segs, Lk_fixed);
+    const int Lq = P.Lq, Lk = P.Lk;
+    const int NT = Lk > 16 ? 2 : 1;
+    const float* qb = q + P.qrow * ldq + P.h * 64;
+    const float* kb = k + P.krow * ldk + P.h * 64;
+    const float* vb = v + P.krow * ldv + P.h * 64;
+    RowFrag qf;
+    frag_load(qf, qb, ldq, n, n < Lq, g);
+    // S in the T layout: lane (n, g) reg r of tile t = S[i = n][j = 16t + 4g + r]
+    float s[2][4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t < NT) {
+            RowFrag kf;
+            frag_load(kf, kb, ldk, 16 * t + n, 16 * t + n < Lk, g);
+            const f32x4 acc = frag_dot(kf, qf);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * g + r;
+                const bool valid = j < Lk && !(causal && j > n);
+                s[t][r] = valid ? acc[r] * scale : -INFINITY;
+                m = fmaxf(m, s[t][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = -INFINITY;
+        }
+    }
+    m = grp_max_hi(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[t][r] = s[t][r] == -INFINITY ? 0.f : __expf(s[t][r] - m);
+            sum += s[t][r];
+        }
+    sum = grp_sum_hi(sum);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    const uint64_t sd = thresh ? *seed : 0;
+    float* pg = p_out + P.pbase;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r;
+            float pv = s[t][r] * inv;
+            if (n < Lq && j < Lk) {
+                pg[(long)n * Lk + j] = pv;
+                if (thresh) pv = sbl_keep(sd, offset, (uint64_t)P.pbase + (uint64_t)n * Lk + j, thresh) ? pv * keep_scale : 0.f;
+            } else {
+                pv = 0.f;
+            }
+            s[t][r] = pv;
+        }
+    // O = Pd V: contraction over keys; lane (n, g) supplies A = Pd[i = n][j(g)], B = V[j(g)][4n + e]
+    f32x4 oacc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oacc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * g + r;
+                float vv[4];
+                ld4(vv, vb + (long)j * ldv + 4 * n, j < Lk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[e] = MFMA16(s[t][r], vv[e], oacc[e]);
+            }
+        }
+    }
+    float* ob = o + P.qrow * ldo + P.h * 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        if (i < Lq) *reinterpret_cast<float4*>(ob + (long)i * ldo + 4 * n) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_small_bwd_kernel(const float* __restrict__ dout, long lddo, const float* __restrict__ q,
+                                                                  long ldq, const float* __restrict__ k, long ldk,
+                                                                  const float* __restrict__ v, long ldv, const float* __restrict__ p,
+                                                                  float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
+                                                                  float* __restrict__ dv, long lddv, int B, int H, SegDesc segs,
+                                                                  int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
+                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int prob = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (prob >= nprob) return;
+    const SmallProb P = small_prob(prob, B, H, segs, Lk_fixed);
+    const int Lq = P.Lq, Lk = P.Lk;
+    const int NT = Lk > 16 ? 2 : 1;
+    const float* qb = q + P.qrow * ldq + P.h * 64;
+    const float* kb = k + P.krow * ldk + P.h * 64;
+    const float* vb = v + P.krow * ldv + P.h * 64;
+    const float* gb = dout + P.qrow * lddo + P.h * 64;
+    const float* pg = p + P.pbase;
+    const uint64_t sd = thresh ? *seed : 0;
+    const bool kv_atomic = Lk_fixed > 0 && segs.nseg > 1;
+    RowFrag gf;   // dO rows on n
+    frag_load(gf, gb, lddo, n, n < Lq, g);
+    // ---- pass T: dP and P in the T layout (i = n, j = 16t + 4g + r)  ->  dS_T, then dQ = dS K
+    float dsT[2][4];
+    {
+        float pT[2][4], dpT[2][4];
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < NT) {
+                RowFrag vf;
+                frag_load(vf, vb, ldv, 16 * t + n, 16 * t + n < Lk, g);
+                const f32x4 acc = frag_dot(vf, gf);      // [j = 4g + r][i = n]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * g + r;
+                    float pv = 0.f, dp = 0.f;
+                    if (n < Lq && j < Lk) {
+                        pv = pg[(long)n * Lk + j];
+                        dp = acc[r];
+                        if (thresh) dp = sbl_keep(sd, offset, (uint64_t)P.pbase + (uint64_t)n * Lk + j, thresh) ? dp * keep_scale : 0.f;
+                    }
+                    pT[t][r] = pv;
+                    dpT[t][r] = dp;
+                    dot += pv * dp;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pT[t][r] = dpT[t][r] = 0.f;
+            }
+        }
+        dot = grp_sum_hi(dot);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsT[t][r] = pT[t][r] * (dpT[t][r] - dot) * scale;
+    }
+    {
+        f32x4 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * g + r;
+                    float kk[4];
+                    ld4(kk, kb + (long)j * ldk + 4 * n, j < Lk);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = MFMA16(dsT[t][r], kk[e], acc[e]);
+                }
+            }
+        }
+        float* dqb = dq + P.qrow * lddq + P.h * 64;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g + r;
+            if (i < Lq) *reinterpret_cast<float4*>(dqb + (long)i * lddq + 4 * n) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+    }
+    // ---- pass N: the same quantities in the N layout (i = 4g + r, j = 16t + n)  ->  dV = Pd^T dO, dK = dS^T Q
+    float pdN[2][4], dsN[2][4];
+    {
+        float pN[2][4], dpN[2][4];
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < NT) {
+                RowFrag vf;
+                frag_load(vf, vb, ldv, 16 * t + n, 16 * t + n < Lk, g);
+                const f32x4 acc = frag_dot(gf, vf);      // [i = 4g + r][j = n]
+                const int j = 16 * t + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * g + r;
+                    float pv = 0.f, dp = 0.f, pd = 0.f;
+                    if (i < Lq && j < Lk) {
+                        pv = pg[(long)i * Lk + j];
+                        dp = acc[r];
+                        pd = pv;
+                        if (thresh) {
+                            const bool keep = sbl_keep(sd, offset, (uint64_t)P.pbase + (uint64_t)i * Lk + j, thresh);
+                            dp = keep ? dp * keep_scale : 0.f;
+                            pd = keep ? pv * keep_scale : 0.f;
+                        }
+                    }
+                    pN[t][r] = pv;
+                    dpN[t][r] = dp;
+                    pdN[t][r] = pd;
+                    dot[r] += pv * dp;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pN[t][r] = dpN[t][r] = pdN[t][r] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot[r] = grp_sum_lo(dot[r]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsN[t][r] = pN[t][r] * (dpN[t][r] - dot[r]) * scale;
+    }
+    // contraction over queries: slot kk = g stands for i = 4g + r; B rows = dO / Q rows i, columns 4n + e
+    float gq[4][4], qq[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        ld4(gq[r], gb + (long)i * lddo + 4 * n, i < Lq);
+        ld4(qq[r], qb + (long)i * ldq + 4 * n, i < Lq);
+    }
+    float* dvb = dv + P.krow * lddv + P.h * 64;
+    float* dkb = dk + P.krow * lddk + P.h * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t < NT) {
+            f32x4 av[4], ak[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = ak[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    av[e] = MFMA16(pdN[t][r], gq[r][e], av[e]);     // A[row j = n][kk -> i] = Pd[i][j]
+                    ak[e] = MFMA16(dsN[t][r], qq[r][e], ak[e]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * g + r;
+                if (j < Lk) {
+                    float* pv_ = dvb + (long)j * lddv + 4 * n;
+                    float* pk_ = dkb + (long)j * lddk + 4 * n;
+                    if (kv_atomic) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            atomicAdd(pv_ + e, av[e][r]);
+                            atomicAdd(pk_ + e, ak[e][r]);
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(pv_) = make_float4(av[0][r], av[1][r], av[2][r], av[3][r]);
+                        *reinterpret_cast<float4*>(pk_) = make_float4(ak[0][r], ak[1][r], ak[2][r], ak[3][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static bool at_small_ok(const SegDesc& d, int Lk_fixed, int mask_kind) {
+    static const int enabled = getenv("SBL_ATT_SMALL") ? atoi(getenv("SBL_ATT_SMALL")) : 1;   // A/B knob
+    if (!enabled || mask_kind == 2 || Lk_fixed > 32) return false;
+    for (int s = 0; s < d.nseg; ++s)
+        if (d.L[s] > 16) return false;
+    return true;
+}
+
 static int at_check(const char* who, int B, int H, const SegDesc& d, int Lk_fixed, long ldq, long ldk, long ldv, long ldo) {
     SBL_REQUIRE(B > 0 && H > 0 && Lk_fixed >= 0 && Lk_fixed <= 64, "%s: bad B=%d H=%d Lk=%d (Lk <= 64)", who, B, H, Lk_fixed);
     for (int s = 0; s < d.nseg; ++s)
@@ -248,6 +592,15 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
     SBL_REQUIRE(q && k && v && o && p_out && sbl_aligned16(q) && sbl_aligned16(k) && sbl_aligned16(v), "sbl_attention_fwd: null/unaligned pointer");
     SBL_REQUIRE(mask_kind >= 0 && mask_kind <= 2 && (mask_kind != 2 || (mask && nseg == 1)), "sbl_attention_fwd: bad mask");
     SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_attention_fwd: bad dropout args");
+    if (at_small_ok(d, Lk_fixed, mask_kind)) {
+        SBL_REQUIRE(sbl_aligned16(o) && sbl_aligned16(q) && sbl_aligned16(k) && sbl_aligned16(v), "sbl_attention_fwd: unaligned pointer");
+        const int nprob = nseg * B * H;
+        hipLaunchKernelGGL(attention_small_fwd_kernel, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
+                           ldv, o, ldo, p_out, mask_kind == 1, B, H, d, Lk_fixed, scale,
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+        SBL_LAUNCH_CHECK("sbl_attention_fwd(small)");
+        return 0;
+    }
     const size_t lds = sizeof(float) * 4 * AT_SZ;
     static bool attr_set[64] = {false};
     if (int e = at_attr((const void*)attention_fwd_kernel, lds, attr_set)) return e;
@@ -270,6 +623,15 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
     SBL_REQUIRE(dout && q && k && v && p && dq && dk && dv && sbl_aligned16(dout) && sbl_aligned16(q) && sbl_aligned16(k) && sbl_aligned16(v),
                 "sbl_attention_bwd: null/unaligned pointer");
     SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_attention_bwd: bad dropout args");
+    if (at_small_ok(d, Lk_fixed, 0) && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && sbl_aligned16(dq) && sbl_aligned16(dk) &&
+        sbl_aligned16(dv)) {
+        const int nprob = nseg * B * H;
+        hipLaunchKernelGGL(attention_small_bwd_kernel, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, dout, lddo, q, ldq,
+                           k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+        SBL_LAUNCH_CHECK("sbl_attention_bwd(small)");
+        return 0;
+    }
     const size_t lds = sizeof(float) * 6 * AT_SZ;
     static bool attr_set[64] = {false};
     if (int e = at_attr((const void*)attention_bwd_kernel, lds, attr_set)) return e;

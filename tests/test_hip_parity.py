@@ -464,6 +464,90 @@ def test_embed_argmax_adam_rowscale(ops, golden_modules):
     assert maxdiff(ops.RowScaleFn.apply(x, s), x * s) == 0.0
 
 
+def _seg_attention(ops, q, k, v, B, H, segL, Lk_fixed, causal, drop_p, seed, offset):
+    """sbl_attention_seg_fwd through the C ABI; q rows are the ragged (segment, b, l) rows, k/v likewise (self) or
+    (B*Lk_fixed) rows (cross).  Returns (o, p)."""
+    import ctypes
+    arr = (ctypes.c_int * len(segL))(*segL)
+    HD = H * 64
+    o = torch.empty_like(q)
+    np_ = sum(H * B * L * (Lk_fixed or L) for L in segL)
+    p = torch.empty(np_, device=DEV)
+    ops.call("sbl_attention_seg_fwd", q.data_ptr(), HD, k.data_ptr(), HD, v.data_ptr(), HD, o.data_ptr(), HD, p.data_ptr(),
+             1 if causal else 0, None, B, H, arr, len(segL), Lk_fixed, 0.125, drop_p, seed.data_ptr() if drop_p else None, offset, ops._s())
+    return o, p
+
+
+def _seg_attention_bwd(ops, do, q, k, v, p, B, H, segL, Lk_fixed, drop_p, seed, offset):
+    import ctypes
+    arr = (ctypes.c_int * len(segL))(*segL)
+    HD = H * 64
+    dq = torch.empty_like(q)
+    shared = Lk_fixed > 0 and len(segL) > 1
+    dk = torch.zeros_like(k) if shared else torch.empty_like(k)
+    dv = torch.zeros_like(v) if shared else torch.empty_like(v)
+    ops.call("sbl_attention_seg_bwd", do.data_ptr(), HD, q.data_ptr(), HD, k.data_ptr(), HD, v.data_ptr(), HD, p.data_ptr(),
+             dq.data_ptr(), HD, dk.data_ptr(), HD, dv.data_ptr(), HD, B, H, arr, len(segL), Lk_fixed, 0.125, drop_p,
+             seed.data_ptr() if drop_p else None, offset, ops._s())
+    return dq, dk, dv
+
+
+@pytest.mark.parametrize("segL,Lk_fixed,causal", [((3, 16, 9), 0, True), ((1, 2), 0, False), ((5, 16, 7, 1), 29, False),
+                                                  ((16,), 32, False), ((4,), 13, False), ((12, 20), 29, False)])
+def test_segmented_attention_decoder_sizes(ops, segL, Lk_fixed, causal):
+    """The ragged attention entry points at decoder sizes (<= 16 queries, <= 32 keys take the one-wavefront-per-problem
+    kernels; the (12, 20) case the workgroup kernel) against fp64 torch, forward and backward, plus the dropout path
+    through exact algebraic properties: O is linear in V under a fixed mask and <dO, O> = <dV, V> (adjoint)."""
+    B, H = 3, 2
+    HD = H * 64
+    R = B * sum(segL)
+    q = U("sa.q%d" % R, (R, HD)).to(DEV)
+    if Lk_fixed:
+        k, v = U("sa.k%d" % Lk_fixed, (B * Lk_fixed, HD)).to(DEV), U("sa.v%d" % Lk_fixed, (B * Lk_fixed, HD)).to(DEV)
+    else:
+        k, v = U("sa.ks%d" % R, (R, HD)).to(DEV), U("sa.vs%d" % R, (R, HD)).to(DEV)
+    do = U("sa.do%d" % R, (R, HD)).to(DEV)
+    seed = torch.tensor([1234567], dtype=torch.int64, device=DEV)
+    o, p = _seg_attention(ops, q, k, v, B, H, segL, Lk_fixed, causal, 0.0, seed, 0)
+    dq, dk, dv = _seg_attention_bwd(ops, do, q, k, v, p, B, H, segL, Lk_fixed, 0.0, seed, 0)
+    qr, kr, vr = (t.detach().cpu().double().requires_grad_(True) for t in (q, k, v))
+    outs, off, poff = [], 0, 0
+    for L in segL:
+        Lk = Lk_fixed or L
+        qs = qr[off:off + B * L].view(B, L, H, 64).permute(2, 0, 1, 3)
+        ks = (kr.view(B, Lk, H, 64) if Lk_fixed else kr[off:off + B * L].view(B, L, H, 64)).permute(2, 0, 1, 3)
+        vs = (vr.view(B, Lk, H, 64) if Lk_fixed else vr[off:off + B * L].view(B, L, H, 64)).permute(2, 0, 1, 3)
+        sc = qs @ ks.transpose(-1, -2) * 0.125
+        if causal:
+            sc = sc.masked_fill(torch.triu(torch.ones(L, Lk, dtype=torch.bool), 1), float("-inf"))
+        pr = torch.softmax(sc, -1)
+        assert maxdiff(p[poff:poff + H * B * L * Lk].view(H, B, L, Lk), pr.detach()) < 2e-6      # (H*B, L, Lk) like the reference
+        outs.append((pr @ vs).permute(1, 2, 0, 3).reshape(B * L, HD))
+        off += B * L
+        poff += H * B * L * Lk
+    oref = torch.cat(outs, 0)
+    assert maxdiff(o, oref.detach()) < 5e-6
+    (oref * do.cpu().double()).sum().backward()
+    assert maxdiff(dq, qr.grad) < 2e-5 and maxdiff(dk, kr.grad) < 2e-5 and maxdiff(dv, vr.grad) < 2e-5
+    # dropout 0.3, fixed (seed, offset): linearity in V and the adjoint identity hold exactly for the masked operator
+    v2 = U("sa.v2%d" % v.size(0), tuple(v.shape)).to(DEV)
+    o1, p1 = _seg_attention(ops, q, k, v, B, H, segL, Lk_fixed, causal, 0.3, seed, 7)
+    o2, _ = _seg_attention(ops, q, k, v2, B, H, segL, Lk_fixed, causal, 0.3, seed, 7)
+    o12, _ = _seg_attention(ops, q, k, v + v2, B, H, segL, Lk_fixed, causal, 0.3, seed, 7)
+    assert maxdiff(p1, p) < 1e-6 and maxdiff(o12, o1 + o2) < 1e-5 and maxdiff(o1, o) > 1e-3
+    _, _, dv1 = _seg_attention_bwd(ops, do, q, k, v, p1, B, H, segL, Lk_fixed, 0.3, seed, 7)
+    lhs, rhs = float((do.double() * o1.double()).sum()), float((dv1.double() * v.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    # d<dO, O>/dQ along a direction, central differences in fp32 inputs / fp64 accumulation
+    dq1, _, _ = _seg_attention_bwd(ops, do, q, k, v, p1, B, H, segL, Lk_fixed, 0.3, seed, 7)
+    dirq = U("sa.dir%d" % R, (R, HD)).to(DEV)
+    eps = 1e-2
+    fp = float((do.double() * _seg_attention(ops, q + eps * dirq, k, v, B, H, segL, Lk_fixed, causal, 0.3, seed, 7)[0].double()).sum())
+    fm = float((do.double() * _seg_attention(ops, q - eps * dirq, k, v, B, H, segL, Lk_fixed, causal, 0.3, seed, 7)[0].double()).sum())
+    ana = float((dq1.double() * dirq.double()).sum())
+    assert abs((fp - fm) / (2 * eps) - ana) < 2e-3 * max(1.0, abs(ana))
+
+
 def test_dropout_statistics_and_replay(ops):
     x = torch.ones(1 << 20, device=DEV, requires_grad=True)
     st = ops.dropout_state(x.device)

@@ -1,0 +1,34 @@
+"""Timeline report of one bench step from a rocprofv3 --kernel-trace CSV: phase boundaries, per-phase kernel mix."""
+import csv, collections, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('stem_conv_fwd')]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+a, b = idx[which], idx[which + 1]
+step = rows[a:b]
+t0 = int(step[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in step)
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in step)
+cov = 0; cs, ce = ev[0]
+for s, e in ev[1:]:
+    if s > ce: cov += ce - cs; cs, ce = s, e
+    else: ce = max(ce, e)
+cov += ce - cs
+print("step wall %.2f ms, %d kernels, union busy %.2f ms, sum %.2f ms" % ((t1 - t0) / 1e6, len(step), cov / 1e6, sum(e - s for s, e in ev) / 1e6))
+def short(n):
+    n = re.sub(r'\(.*', '', n)
+    return n.replace('void ', '').replace('sbl_mfma_gemm_kernel', 'G').replace('sbl_skinny_gemm_kernel', 'SK')[:72]
+def first(name): return next(((int(r['Start_Timestamp']) - t0) / 1e6 for r in step if name in r['Kernel_Name']), None)
+def last(name): return next(((int(r['End_Timestamp']) - t0) / 1e6 for r in reversed(step) if name in r['Kernel_Name']), None)
+marks = [("frontend fwd", 0.0), ("encoder fwd", last('avgpool_fwd') or first('avgpool')), ("decoder fwd", first('embed_pe')),
+         ("decoder bwd", first('smoothed_ce_bwd') or first('smoothed_ce')), ("frontend bwd", first('avgpool_bwd')), ("tail", last('stem_wgrad')), ("end", (t1 - t0) / 1e6)]
+print(marks)
+for (nm, lo), (_, hi) in zip(marks[:-1], marks[1:]):
+    if lo is None or hi is None: continue
+    w = [r for r in step if lo <= (int(r['Start_Timestamp']) - t0) / 1e6 < hi]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in w:
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        agg[short(r['Kernel_Name'])][0] += 1; agg[short(r['Kernel_Name'])][1] += d
+    print("=== %s [%.2f, %.2f) = %.2f ms wall: %d kernels, sum %.2f ms" % (nm, lo, hi, hi - lo, len(w), sum(v[1] for v in agg.values()) / 1e3))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 10]:
+        print("   %-74s %5d %8.2f ms  avg %6.1f us" % (k, v[0], v[1] / 1e3, v[1] / v[0]))
