@@ -1,4 +1,4 @@
-export MS=${MS:-1440,4352}
-for cfg in "SBL_SEG_TILE=64 SBL_SEG_KU=2" "SBL_SEG_TILE=64 SBL_SEG_KU=4" "SBL_SEG_TILE=128" "SBL_SEG_TILE=128 SBL_SEG_TARGET=512" "SBL_SEG_TILE=64 SBL_SEG_KU=2 SBL_SEG_TARGET=512"; do
-echo "== $cfg"; env $cfg timeout -k 10 120 python tools/bench_gemm2.py 2>&1 | grep "M=" | cut -c1-22,108- || exit 1
+export MS=${MS:-480,960,1440}
+for cfg in "X=1" "SBL_SKINNY_MAX_M=1500 SBL_SKINNY_MAX_TILES=4096"; do
+echo "== $cfg"; env $cfg timeout -k 10 120 python tools/bench_gemm2.py 2>&1 | grep "M=" | cut -c1-107 || exit 1
 done
