@@ -114,7 +114,8 @@ int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const floa
  * reference's OIHW parameter layout (state-dict shapes stay the reference's). */
 int sbl_conv_weight_pack(const float* w_oihw, float* w_ohwi, float* w_dgrad /*[Cin][KH][KW][Cout] or NULL*/, int Cout,
                          int Cin, int KH, int KW, sbl_stream_t stream);
-int sbl_conv_wgrad_unpack(const float* dw_ohwi, float* dw_oihw, int Cout, int Cin, int KH, int KW,
+/* accumulate != 0: dw_oihw += (the persistent flat gradient buffer of a data-parallel replica) */
+int sbl_conv_wgrad_unpack(const float* dw_ohwi, float* dw_oihw, int Cout, int Cin, int KH, int KW, int accumulate,
                           sbl_stream_t stream);
 /* stats: NULL or double[2*Cout] (sum, sumsq of y) accumulated by the epilogue; zeroed by the call */
 int sbl_conv2d_fwd(const float* x, const float* w_ohwi, float* y, double* stats, int NIMG, int H, int W, int Cin,

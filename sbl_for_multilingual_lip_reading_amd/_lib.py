@@ -24,7 +24,7 @@ SIGNATURES = {
     "sbl_bn_bwd_reduce": [P, P, P, P, P, P, L, I, I, P],
     "sbl_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, P],
     "sbl_conv_weight_pack": [P, P, P, I, I, I, I, P],
-    "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, P],
+    "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, I, P],
     "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],

@@ -113,7 +113,7 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, float* __restric
     }
 }
 __global__ void wgrad_unpack_kernel(const float* __restrict__ ohwi, float* __restrict__ oihw, int Cout, int Cin, int KH,
-                                    int KW) {
+                                    int KW, int accumulate) {
     long n = (long)Cout * Cin * KH * KW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         // i indexes OIHW
@@ -123,7 +123,8 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ ohwi, float* __res
         t /= KH;
         int ci = t % Cin;
         int co = t / Cin;
-        oihw[i] = ohwi[(((long)co * KH + kh) * KW + kw) * Cin + ci];
+        const float g = ohwi[(((long)co * KH + kh) * KW + kw) * Cin + ci];
+        oihw[i] = accumulate ? oihw[i] + g : g;
     }
 }
 extern "C" int sbl_conv_weight_pack(const float* w, float* ohwi, float* wt, int Cout, int Cin, int KH, int KW,
@@ -135,12 +136,12 @@ extern "C" int sbl_conv_weight_pack(const float* w, float* ohwi, float* wt, int 
     SBL_LAUNCH_CHECK("sbl_conv_weight_pack");
     return 0;
 }
-extern "C" int sbl_conv_wgrad_unpack(const float* ohwi, float* oihw, int Cout, int Cin, int KH, int KW,
+extern "C" int sbl_conv_wgrad_unpack(const float* ohwi, float* oihw, int Cout, int Cin, int KH, int KW, int accumulate,
                                      sbl_stream_t stream) {
     SBL_REQUIRE(ohwi && oihw && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "sbl_conv_wgrad_unpack: bad args");
     long n = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(sbl_cdiv(n, 256) > 2048 ? 2048 : sbl_cdiv(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, ohwi, oihw, Cout, Cin, KH, KW);
+                       (hipStream_t)stream, ohwi, oihw, Cout, Cin, KH, KW, accumulate);
     SBL_LAUNCH_CHECK("sbl_conv_wgrad_unpack");
     return 0;
 }

@@ -116,6 +116,24 @@ def _xs_out(*ts):
                     t.record_stream(main)
 
 
+CONV_WGRAD_SIDE = os.environ.get("SBL_CONV_WGRAD_SIDE", "1") != "0"
+_side_join = {"armed": False}
+
+
+def _arm_side_join():
+    """Once per backward: make the stream that finishes backward wait for the side stream."""
+    if not _side_join["armed"]:
+        _side_join["armed"] = True
+
+        def join():
+            _side_join["armed"] = False
+            cur = torch.cuda.current_stream()
+            side = _side_streams.get(cur.device_index)
+            if side is not None and side != cur:
+                cur.wait_stream(side)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 def _side_to_main():
     """Explicit fence when a side-stream tape node hands its result to the main stream (belt and braces next to the
     autograd engine's own producer/consumer event)."""
@@ -1004,10 +1022,29 @@ class ConvBNFn(torch.autograd.Function):
             call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
             dx = torch.empty_like(x)
             call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+        gw = _gbuf(w)
+        if gw is not None and CONV_WGRAD_SIDE:
+            # the weight gradient is off backward's dependency chain: with a persistent gradient buffer it is issued
+            # on the second stream, where its workgroups fill the CUs that the chain's kernels (tile-count
+            # quantisation: 522 workgroups on 256 CUs) leave idle; joined by an end-of-backward engine callback
+            cur = torch.cuda.current_stream()
+            side = side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+                call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+                call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
+            x.record_stream(side)
+            dconv.record_stream(side)
+            _arm_side_join()
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None
         dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+        if gw is not None:
+            call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None
         dw = torch.empty_like(w)
-        call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(dw), Cout, Cin, KH, KW, _s())
+        call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(dw), Cout, Cin, KH, KW, 0, _s())
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
 

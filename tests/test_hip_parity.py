@@ -123,8 +123,10 @@ def test_conv2d_fwd_dgrad_wgrad(ops, NIMG, H, W, Cin, Cout, k, stride):
     ops.call("sbl_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), NIMG, H, W, Cin, Cout, k, k, stride, pad,
              ops._s())
     dw = torch.empty(Cout, Cin, k, k, device=DEV)
-    ops.call("sbl_conv_wgrad_unpack", dwd.data_ptr(), dw.data_ptr(), Cout, Cin, k, k, ops._s())
+    ops.call("sbl_conv_wgrad_unpack", dwd.data_ptr(), dw.data_ptr(), Cout, Cin, k, k, 0, ops._s())
     assert relerr(dw, w.grad) < 2e-5      # split-K float atomics over NIMG*Ho*Wo pixels
+    ops.call("sbl_conv_wgrad_unpack", dwd.data_ptr(), dw.data_ptr(), Cout, Cin, k, k, 1, ops._s())     # += form
+    assert relerr(dw, 2 * w.grad) < 2e-5
 
 
 # --------------------------------------------------------------------------- stem
@@ -771,11 +773,13 @@ def test_fused_adam_training_steps_match_torch_adam(ops):
     p1 = dict(m1.named_parameters())
     # Adam's first steps move every element by ~lr*sign(g): elements whose gradient is rounding noise (e.g. the
     # analytically-zero K-bias gradients, BN-amplified frontend noise) can take the opposite sign in the two
-    # summation orders, so compare the matrices of the transformer in relative L2, not element-wise
+    # summation orders, so compare the matrices of the transformer in relative L2, not element-wise.  Two runs of the
+    # SAME optimizer differ by 1e-5 or by 2.6e-3 depending on whether such a flip happens (float-atomic summation
+    # order; measured with tools/debug_adam.py), hence the 1e-2 bound.
     for n, p in m2.named_parameters():
         if (n.startswith("decoder") or n.startswith("encoder")) and p.dim() >= 2:
             num = float((p - p1[n]).norm())
-            assert num < 2e-3 * float(p1[n].norm()) + 1e-6, (n, num)
+            assert num < 1e-2 * float(p1[n].norm()) + 1e-6, (n, num)
 
 
 @pytest.mark.parametrize("tag", ["small", "full"])
