@@ -22,7 +22,7 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     SBL_REQUIRE(x && w && y && sbl_aligned16(x) && sbl_aligned16(w), "sbl_conv2d_fwd: null/unaligned pointer");
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
     const int M = NIMG * Ho * Wo, N = Cout, K = KH * KW * Cin;
-    ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad};
+    ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};
@@ -52,8 +52,44 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
     if (int e = check_conv("sbl_conv2d_dgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(dy && wt && dx && sbl_aligned16(dy) && sbl_aligned16(wt), "sbl_conv2d_dgrad: null/unaligned pointer");
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
+    static const int use_classes = getenv("SBL_DGRAD_CLASSES") ? atoi(getenv("SBL_DGRAD_CLASSES")) : 1;   // A/B knob
+    if (stride == 2 && use_classes) {
+        // Input pixel (ih, iw) only receives taps with kh = ih + pad (mod 2), kw likewise: 1 + 2 + 2 + 4 of the 9 taps
+        // over the four parity classes (3x3), or the even/even class alone (1x1).  One dense implicit GEMM per class
+        // (rows = the class's pixels, k = its taps) does 1/4 of the work of gathering zeros for the other taps.
+        const int N = Cin;
+        if (KH == 1) SBL_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)NIMG * H * W * Cin, s));
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                ConvGeom g{NIMG, (H - ph + 1) / 2, (W - pw + 1) / 2, Ho, Wo, Cout, KH, KW, stride, pad, 1, ph, pw, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                int lin[4] = {0, 0, 0, 0};
+                for (int kh = 0; kh < KH; ++kh)
+                    for (int kw = 0; kw < KW; ++kw)
+                        if (((ph + pad - kh) & 1) == 0 && ((pw + pad - kw) & 1) == 0) {
+                            g.tkh[g.ntaps] = kh; g.tkw[g.ntaps] = kw; lin[g.ntaps] = kh * KW + kw;
+                            ++g.ntaps;
+                        }
+                const int M = NIMG * g.OH * g.OW, K = g.ntaps * Cout;
+                if (g.ntaps == 0 || M == 0) continue;
+                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
+                const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+#define SBL_CONV_DGC(BM, BN)                                                                                  \
+    do {                                                                                                      \
+        ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
+        DenseKCTaps<BN> bl{wt, (long)KH * KW * Cout, N, Cout, {lin[0], lin[1], lin[2], lin[3]}};              \
+        EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 1, g.OH, g.OW, H, W, ph, pw};      \
+        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+    } while (0)
+                if (N >= 128 && t128 >= 512) SBL_CONV_DGC(128, 128);
+                else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_DGC(128, 64);
+                else SBL_CONV_DGC(64, 64);
+#undef SBL_CONV_DGC
+                SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(class)");
+            }
+        return 0;
+    }
     const int M = NIMG * H * W, N = Cin, K = KH * KW * Cout;
-    ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad};
+    ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
 #define SBL_CONV_DG(BM, BN)                                                                                   \
@@ -78,7 +114,7 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     SBL_REQUIRE(x && dy && dw && sbl_aligned16(x) && sbl_aligned16(dy), "sbl_conv2d_wgrad: null/unaligned pointer");
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
     const int M = Cout, N = KH * KW * Cin, K = NIMG * Ho * Wo;   // reduce over output pixels
-    ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad};
+    ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * N, s));
     // split the pixel reduction so that ~1024 workgroups are in flight; chunks stay >= 256 pixels
     const long tiles = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);

@@ -78,6 +78,62 @@ struct DenseKC {
     }
 };
 
+// Dense k-contiguous rows whose k axis is a SUBSET of C-wide blocks of the stored row: GEMM-k block t (k in
+// [t*C, (t+1)*C)) lives at stored block lin[t].  Used for the weight operand of the parity-class input gradients
+// (the class's taps out of the [Cin][KH*KW][Cout] rows).  C % 16 == 0, so a BK slice never straddles a block.
+template <int BR>
+struct DenseKCTaps {
+    static constexpr bool kColSum = false;
+    const float* p;
+    long ld;
+    int rows;
+    int C;
+    int lin[4];
+    struct State {
+        const float* rp[BR / 64];
+        bool ok[BR / 64];
+        int kq;
+    };
+    struct Regs {
+        float4 v[BR / 64];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.kq = (tid & 3) * 4;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            int r = r0 + ps * 64 + (tid >> 2);
+            s.ok[ps] = r < rows;
+            s.rp[ps] = p + (long)(s.ok[ps] ? r : 0) * ld;
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+        const int t = k0 / C;              // block-uniform
+        int l = lin[0];
+#pragma unroll
+        for (int u = 1; u < 4; ++u)
+            if (u == t) l = lin[u];
+        const int k = l * C + (k0 - t * C) + s.kq;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s.ok[ps] && k0 < kend) v = *reinterpret_cast<const float4*>(s.rp[ps] + k);
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            const int row = ps * 64 + (tid >> 2);
+            lds[s.kq + 0][row] = r.v[ps].x;
+            lds[s.kq + 1][row] = r.v[ps].y;
+            lds[s.kq + 2][row] = r.v[ps].z;
+            lds[s.kq + 3][row] = r.v[ps].w;
+        }
+    }
+};
+
 // Dense, m-contiguous: element (r,k) at p[k*ld + r].  Used for dY^T / X in weight-gradient
 // GEMMs and for W[K,N] in input-gradient GEMMs.
 template <int BR, bool VEC>
@@ -207,6 +263,11 @@ struct ConvGeom {
     int NIMG, OH, OW;   // GEMM-row grid
     int SH, SW, C;      // gathered tensor (NHWC)
     int KH, KW, stride, pad;
+    // stride-2 input-gradient parity classes (cls != 0): the GEMM rows are the input pixels (2a + ph, 2b + pw) only,
+    // OH/OW are that sub-grid's dims, and GEMM-k runs over the ntaps <= 4 taps (tkh[t], tkw[t]) that can reach
+    // such a pixel (kh = ph + pad mod 2, kw likewise) instead of over all KH*KW taps, 3/4 of which would gather zeros.
+    int cls, ph, pw, ntaps;
+    int tkh[4], tkw[4];
 };
 
 template <bool DGRAD>
@@ -216,6 +277,10 @@ __device__ __forceinline__ bool conv_src_coord(const ConvGeom& g, int oh, int ow
         iw = ow * g.stride - g.pad + kw;
         return (unsigned)ih < (unsigned)g.SH && (unsigned)iw < (unsigned)g.SW;
     } else {
+        if (g.cls) {
+            oh = 2 * oh + g.ph;
+            ow = 2 * ow + g.pw;
+        }
         int th = oh + g.pad - kh, tw = ow + g.pad - kw;
         if (th < 0 || tw < 0) return false;
         if (g.stride == 2) {
@@ -263,7 +328,13 @@ struct ConvGatherKC {
     __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
         const int tap = k0 / g.C;          // block-uniform
         const int c = k0 - tap * g.C + s.kq;
-        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        int kh = tap / g.KW, kw = tap - kh * g.KW;
+        if (DGRAD && g.cls) {
+            kh = g.tkh[0]; kw = g.tkw[0];
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+                if (t == tap) { kh = g.tkh[t]; kw = g.tkw[t]; }
+        }
 #pragma unroll
         for (int ps = 0; ps < BR / 64; ++ps) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -354,6 +425,16 @@ struct EpiStore {
     double* stats;       // [2*N] (sum, sumsq) when STATS
     const float* relu_mask;   // multiply by (mask[m*ldm+n] > 0) (ReLU backward) or nullptr
     long ldm;
+    // optional output row map for the parity-class input gradients: GEMM row m = (img, a, b) of the class sub-grid
+    // (ca x cb) is pixel (2a + ph, 2b + pw) of the (cH x cW) image; cmap == 0: row m is output row m
+    int cmap, ca, cb, cH, cW, cph, cpw;
+    __device__ __forceinline__ long row_off(int m) const {
+        if (!cmap) return (long)m * ldc;
+        const int img = m / (ca * cb);
+        const int rem = m - img * (ca * cb);
+        const int a = rem / cb, b = rem - a * cb;
+        return (((long)img * cH + 2 * a + cph) * cW + 2 * b + cpw) * ldc;
+    }
     __device__ __forceinline__ void tile(const f32x16& a, int mbase, int n, int M, int N, int lane,
                                          float& s1, float& s2) const {
         if (n >= N) return;
@@ -365,7 +446,7 @@ struct EpiStore {
                 float v = a[r] + b;
                 if (relu) v = fmaxf(v, 0.f);
                 if (relu_mask) v = relu_mask[(long)m * ldm + n] > 0.f ? v : 0.f;
-                float* q = C + (long)m * ldc + n;
+                float* q = C + row_off(m) + n;
                 if (MODE == 0) *q = v;
                 else if (MODE == 1) *q += v;
                 else atomicAdd(q, v);
