@@ -100,9 +100,11 @@ int sbl_bn_eval_stats(const float* running_mean, const float* running_var, float
 /* y = [relu]( gamma*(x-mean)*invstd + beta [+ res] ), NHWC rows x C */
 int sbl_bn_apply_fwd(const float* x, const float* res, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, float* y, long rows, int C, int relu, sbl_stream_t stream);
-/* sums = double[2C] (sum g, sum g*xhat), g = dy * (y>0 if relu); zeroed by the call */
+/* sums = double[2C] (sum g, sum g*xhat), g = dy * (y>0 if relu); overwritten by the call.
+ * ws: NULL or the calling stream's sbl_gemm_f32 workspace (>= 16 KiB of int counters that are zero between launches,
+ * then fp32 scratch): block partials + a last-arriver reduction replace 2C contended double atomics per block. */
 int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      double* sums, long rows, int C, int relu, sbl_stream_t stream);
+                      double* sums, long rows, int C, int relu, void* ws, long ws_bytes, sbl_stream_t stream);
 /* dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (if non-null); dgamma, dbeta from sums */
 int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const double* sums, float* dx, float* dres, float* dgamma, float* dbeta,

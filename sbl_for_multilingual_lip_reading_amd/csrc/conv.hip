@@ -38,8 +38,13 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
             sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
         }                                                                                                      \
     } while (0)
-    if (N >= 128 && t128 >= 512) SBL_CONV_FWD(128, 128);
-    else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_FWD(128, 64);
+    // all tiles are co-resident (<= 4 workgroups per CU), so the launch lasts as long as the fullest CU: pick the
+    // largest tile whose count per CU (256 CUs) does not round up by more than ~20 % (522 128x128 tiles = 2.04/CU
+    // would run at 3/CU speed; 1044 128x64 tiles = 4.08/CU at 5/CU)
+    static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
+    const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
+    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_FWD(128, 128);
+    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_FWD(128, 64);
     else SBL_CONV_FWD(64, 64);
 #undef SBL_CONV_FWD
     SBL_LAUNCH_CHECK("sbl_conv2d_fwd");
@@ -99,8 +104,10 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
         EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
         sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
     } while (0)
-    if (N >= 128 && t128 >= 512) SBL_CONV_DG(128, 128);
-    else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_DG(128, 64);
+    static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
+    const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
+    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_DG(128, 128);
+    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG(128, 64);
     else SBL_CONV_DG(64, 64);
 #undef SBL_CONV_DG
     SBL_LAUNCH_CHECK("sbl_conv2d_dgrad");

@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* __restrict__ sums,
-                                                            long rows, int C, int relu, int rows_per_block) {
+                                                            long rows, int C, int relu, int rows_per_block,
+                                                            float* __restrict__ part, int* __restrict__ ticket) {
     // blockDim = 256 = rg row-groups x C4 channel quads (C4 = C/4 divides 256)
     __shared__ float red[256][8];
+    __shared__ int s_last;
     const int C4 = C / 4;
     const int rg = 256 / C4;                      // row groups per block
     const int q0 = threadIdx.x % C4, g0 = threadIdx.x / C4;
@@ -50,22 +52,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
         float sg[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
-        for (long r = r0 + g0; r < r1; r += rg) {
-            const long o = r * C + c;
-            float4 g = *reinterpret_cast<const float4*>(dy + o);
+        auto fold = [&](float4 g, const float4& yy, const float4& v) {
             if (relu) {
-                const float4 yy = *reinterpret_cast<const float4*>(y + o);
                 if (!(yy.x > 0.f)) g.x = 0.f;
                 if (!(yy.y > 0.f)) g.y = 0.f;
                 if (!(yy.z > 0.f)) g.z = 0.f;
                 if (!(yy.w > 0.f)) g.w = 0.f;
             }
-            const float4 v = *reinterpret_cast<const float4*>(x + o);
             sg[0] += g.x; sg[1] += g.y; sg[2] += g.z; sg[3] += g.w;
             sx[0] += g.x * (v.x - mu.x) * is.x;
             sx[1] += g.y * (v.y - mu.y) * is.y;
             sx[2] += g.z * (v.z - mu.z) * is.z;
             sx[3] += g.w * (v.w - mu.w) * is.w;
+        };
+        long r = r0 + g0;
+        const long step = (long)rg * C;
+        for (; r + 3L * rg < r1; r += 4L * rg) {      // 4 rows = 12 independent float4 loads in flight per lane
+            const long o = r * C + c;
+            float4 g[4], yy[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = *reinterpret_cast<const float4*>(dy + o + u * step);
+                v[u] = *reinterpret_cast<const float4*>(x + o + u * step);
+                yy[u] = relu ? *reinterpret_cast<const float4*>(y + o + u * step) : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold(g[u], yy[u], v[u]);
+        }
+        for (; r < r1; r += rg) {
+            const long o = r * C + c;
+            const float4 g = *reinterpret_cast<const float4*>(dy + o);
+            const float4 v = *reinterpret_cast<const float4*>(x + o);
+            const float4 yy = relu ? *reinterpret_cast<const float4*>(y + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+            fold(g, yy, v);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -80,10 +99,65 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 8; ++k) t[k] += red[g * C4 + threadIdx.x][k];
         const int c = threadIdx.x * 4;
+        if (part) {       // block partial -> workspace row [blockIdx.x][2C]
+            float* pr = part + (long)blockIdx.x * 2 * C;
+            *reinterpret_cast<float4*>(pr + c) = make_float4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<float4*>(pr + C + c) = make_float4(t[4], t[5], t[6], t[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                atomicAdd(sums + c + k, (double)t[k]);
+                atomicAdd(sums + C + c + k, (double)t[4 + k]);
+            }
+        }
+    }
+    if (!part) return;
+    // the block that draws the last ticket sums the partials in block order (deterministic, no data atomics);
+    // same release / acquire protocol as the split-K GEMM (mfma_gemm.h)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (tk == (int)gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // 2C/4 float4 columns x G block-groups = 256 lanes; group sums are combined through LDS in group order
+    __shared__ double comb[256][4];
+    const int Q = C / 2, G = 256 / Q;
+    const int qq = threadIdx.x % Q, gi = threadIdx.x / Q;
+    const int nb = (int)gridDim.x;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* pq = part + 4 * qq;
+    int b = gi;
+    for (; b + 3 * G < nb; b += 4 * G) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(pq + (long)(b + u * G) * 2 * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w; }
+    }
+    for (; b < nb; b += G) {
+        const float4 v = *reinterpret_cast<const float4*>(pq + (long)b * 2 * C);
+        a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) comb[threadIdx.x][k] = a[k];
+    __syncthreads();
+    if (gi == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(sums + c + k, (double)t[k]);
-            atomicAdd(sums + C + c + k, (double)t[4 + k]);
+            double t = 0.0;
+            for (int g2 = 0; g2 < G; ++g2) t += comb[g2 * Q + qq][k];
+            sums[4 * qq + k] = t;
         }
     }
 }
@@ -148,16 +222,31 @@ extern "C" int sbl_bn_apply_fwd(const float* x, const float* res, const float* m
 }
 
 extern "C" int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                                 double* sums, long rows, int C, int relu, sbl_stream_t stream) {
+                                 double* sums, long rows, int C, int relu, void* ws, long ws_bytes, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     SBL_REQUIRE(dy && x && mean && invstd && sums && rows > 0 && C >= 4 && C % 4 == 0 && (!relu || y), "sbl_bn_bwd_reduce: bad args");
     SBL_REQUIRE((C / 4) <= 256 && 256 % (C / 4) == 0, "sbl_bn_bwd_reduce: C=%d unsupported (C/4 must divide 256)", C);
-    SBL_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
-    long blocks = (rows + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
+    SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= 16384), "sbl_bn_bwd_reduce: workspace unaligned or < 16 KiB");
+    // ws = the stream's GEMM workspace (int counters, all zero between launches, then fp32 slabs): block partials go
+    // to the slabs and the last-arriving block reduces them; without a workspace every block ends with 2*C double
+    // atomics on the same addresses, which serialise (measured 4x slower on the 22x22x64 layer)
+    static const int max_blocks = getenv("SBL_BN_RED_BLOCKS") ? atoi(getenv("SBL_BN_RED_BLOCKS")) : 512;
+    const int rg = 256 / (C / 4);
+    long blocks = (rows + 4L * rg - 1) / (4L * rg);                 // >= 4 rows per lane
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (ws && blocks > 131072 / (2 * C)) blocks = 131072 / (2 * C);     // the last block reads blocks*2C partials
+    if (blocks < 1) blocks = 1;
+    float* part = nullptr;
+    int* ticket = nullptr;
+    if (ws && ws_bytes >= 16384 + blocks * 2L * C * (long)sizeof(float)) {
+        ticket = (int*)ws;
+        part = (float*)((char*)ws + 16384);
+    } else {
+        SBL_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
+    }
     const int rpb = (int)((rows + blocks - 1) / blocks);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0, s, dy, y, x, mean, invstd,
-                       sums, rows, C, relu, rpb);
+                       sums, rows, C, relu, rpb, part, ticket);
     SBL_LAUNCH_CHECK("sbl_bn_bwd_reduce");
     return 0;
 }

@@ -1008,7 +1008,8 @@ class ConvBNFn(torch.autograd.Function):
         dy = dy.contiguous()
         rows = conv.numel() // Cout
         sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-        call("sbl_bn_bwd_reduce", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(sums), rows, Cout, int(relu), _s())
+        call("sbl_bn_bwd_reduce", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(sums), rows, Cout, int(relu),
+             _workspace().data_ptr(), WS_BYTES, _s())
         dconv = torch.empty_like(conv)
         dres = torch.empty_like(conv) if has_res else None
         dgamma = torch.empty(Cout, device=dev, dtype=torch.float32)
