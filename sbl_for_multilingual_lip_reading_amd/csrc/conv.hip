@@ -26,16 +26,16 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};
-#define SBL_CONV_FWD(BM, BN)                                                                                   \
+#define SBL_CONV_FWD(BM, BN, WN)                                                                               \
     do {                                                                                                       \
         ConvGatherKC<BM, false> al{x, g, M};                                                                   \
         DenseKC<BN, true> bl{w, (long)K, N};                                                                   \
         if (stats) {                                                                                           \
             EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0};                                    \
-            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
         } else {                                                                                               \
             EpiStore<0, false> e{y, (long)N, nullptr, 0, nullptr, nullptr, 0};                                 \
-            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
         }                                                                                                      \
     } while (0)
     // all tiles are co-resident (<= 4 workgroups per CU), so the launch lasts as long as the fullest CU: pick the
@@ -43,9 +43,10 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     // would run at 3/CU speed; 1044 128x64 tiles = 4.08/CU at 5/CU)
     static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
     const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
-    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_FWD(128, 128);
-    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_FWD(128, 64);
-    else SBL_CONV_FWD(64, 64);
+    // (a 256x64 tile with 4x1 wavefronts of 64x64 was measured slower than 128x64 on the 64-channel layer: 442 vs 405 us)
+    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_FWD(128, 128, 2);
+    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_FWD(128, 64, 2);
+    else SBL_CONV_FWD(64, 64, 2);
 #undef SBL_CONV_FWD
     SBL_LAUNCH_CHECK("sbl_conv2d_fwd");
     return 0;
@@ -97,18 +98,18 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
     ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
-#define SBL_CONV_DG(BM, BN)                                                                                   \
+#define SBL_CONV_DG(BM, BN, WN)                                                                               \
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
         DenseKC<BN, true> bl{wt, (long)K, N};                                                                 \
         EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
-        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
     } while (0)
     static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
     const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
-    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_DG(128, 128);
-    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG(128, 64);
-    else SBL_CONV_DG(64, 64);
+    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_DG(128, 128, 2);
+    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG(128, 64, 2);
+    else SBL_CONV_DG(64, 64, 2);
 #undef SBL_CONV_DG
     SBL_LAUNCH_CHECK("sbl_conv2d_dgrad");
     return 0;

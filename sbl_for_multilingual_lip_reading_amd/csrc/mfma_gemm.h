@@ -479,16 +479,19 @@ struct SplitCtl {
 // problems (trunk convolutions: 3 workgroups per CU hide the load latency); KU = 4 for the decoder's skinny
 // GEMMs, which run ~1 workgroup per CU and are bound by the global-load latency of each barrier-to-barrier
 // step: 4x the bytes in flight per step, 4x fewer exposed latencies and barriers.
-template <class AL, class BL, class EPI, int BM, int BN, int KU>
+// WN = wavefronts along N (2: the 2x2 layout; 1: four wavefronts stacked along M, e.g. a 256x64 tile whose waves
+// each own 64x64 = the LDS-read intensity of a 128x128 tile for the 64-channel layers).
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2>
 __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
                                                             int kchunk) {
     constexpr int MK = KU * SBL_BK;   // macro step
     __shared__ __attribute__((aligned(16))) float As[2][MK][BM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][MK][BN + 4];
     __shared__ int s_last;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int WM = 4 / WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
@@ -524,8 +527,8 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     }
     __syncthreads();
 
-    const int arow = wm * (BM / 2) + (lane & 31);
-    const int brow = wn * (BN / 2) + (lane & 31);
+    const int arow = wm * (BM / WM) + (lane & 31);
+    const int brow = wn * (BN / WN) + (lane & 31);
     const int kh = lane >> 5;
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += MK) {
@@ -634,10 +637,10 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / 2) + i * 32, n, M, N, lane, s1, s2);
+        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / WM) + i * 32, n, M, N, lane, s1, s2);
         if (EPI::kStats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
@@ -650,12 +653,12 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     sbl_stamp_end(sc.stamp);
 }
 
-template <class AL, class BL, class EPI, int BM, int BN, int KU = 1>
+template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>
 static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int splits,
                                    hipStream_t s, SplitCtl sc = SplitCtl{nullptr, nullptr, nullptr, nullptr}) {
     constexpr int MK = KU * SBL_BK;
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk);
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk);
 }
