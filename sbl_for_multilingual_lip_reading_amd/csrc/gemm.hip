@@ -158,7 +158,11 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
         if (vec) SBL_GO(true, 128, 128, 1);
         else SBL_GO(false, 128, 128, 1);
     } else {
-        static const int ku = getenv("SBL_TILED_KU") ? atoi(getenv("SBL_TILED_KU")) : 4;      // tuning knob
+        // KU = 4 (69 KB of LDS, 2 workgroups per CU) while every workgroup of the launch is resident at once; beyond
+        // 512 workgroups KU = 2 (35 KB, 4 per CU) keeps them all resident instead of running a second, part-filled
+        // round (measured 1440x2048x512: 36.6 vs 46.9 us; tools/sweep_gemm.sh)
+        static const int ku_env = getenv("SBL_TILED_KU") ? atoi(getenv("SBL_TILED_KU")) : 0;      // tuning knob
+        const int ku = ku_env ? ku_env : (tiles64 * splits > 512 ? 2 : 4);
         if (!vec) SBL_GO(false, 64, 64, 1);
         else if (ku == 1) SBL_GO(true, 64, 64, 1);
         else if (ku == 2) SBL_GO(true, 64, 64, 2);
