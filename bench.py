@@ -44,7 +44,8 @@ KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW,
                 3: "sbl_mfma_gemm_kernel 128x128 dense",
                 4: "sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (trunk conv fwd + BN stats)",
                 5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
-                6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)"}
+                6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)",
+                7: "sbl_mfma_gemm_kernel<SegMC,SegMC> (decoder weight grads merged over all stages, split-K atomics)"}
 T_START = time.perf_counter()
 
 
@@ -103,11 +104,14 @@ class LaunchRecorder:
         inner = ops.call
 
         def call(name, *a):
-            inner(name, *a)
             if not self.active:
-                return
+                return inner(name, *a)
+            s0 = self.lib.sbl_profile_last_slot()
+            inner(name, *a)
             if name == "sbl_gemm_f32":
                 fl = 2.0 * a[2] * a[3] * a[4]
+            elif name == "sbl_wgrad_seg_f32":      # merged decoder weight gradient: contracts over all stages' rows
+                fl = 2.0 * a[6] * a[7] * sum(a[5][i] for i in range(a[0]))
             elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_wgrad"):
                 off = 1 if name == "sbl_conv2d_fwd" else 0
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
@@ -115,9 +119,9 @@ class LaunchRecorder:
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
             else:
                 return
-            slot = self.lib.sbl_profile_last_slot()
-            if slot >= 0:
-                self.launches.append((slot, self.lib.sbl_profile_last_kernel(), fl))
+            s1 = self.lib.sbl_profile_last_slot()
+            if s1 > s0:      # a call may make several launches (stride-2 input gradients: one per parity class)
+                self.launches.append((tuple(range(s0 + 1, s1 + 1)), self.lib.sbl_profile_last_kernel(), fl))
         ops.call = call
 
 
@@ -298,7 +302,7 @@ def main():
             run()
         rec.active = False
         used = lib.sbl_profile_end()
-        launches = rec.launches[:used] if graph is not None else rec.launches
+        launches = [l for l in rec.launches if l[0][-1] < used] if graph is not None else rec.launches
         reps = 3
         dur = np.zeros(CAP)
         for _ in range(reps):
@@ -314,10 +318,10 @@ def main():
             s = stamps.cpu().numpy()
             dur += (s[:, 1] - s[:, 0]) / 100.0            # 100 MHz ticks -> microseconds
         dur /= reps
-        for slot, kid, fl in launches:
+        for slots, kid, fl in launches:
             f = fam.setdefault(kid, {"launches": 0, "us": 0.0, "flops": 0.0})
-            f["launches"] += 1
-            f["us"] += float(dur[slot])
+            f["launches"] += len(slots)
+            f["us"] += float(sum(dur[sl] for sl in slots))
             f["flops"] += fl
         log(args, "kernel timing done (%d instrumented launches per step)" % len(launches))
 

@@ -155,7 +155,9 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
 #define SBL_GO(VEC, BM, BN, KU) \
     launch_trans<VEC, BM, BN, KU>(transA, transB, A, lda, B, ldb, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s)
     if (big) {
-        if (vec) SBL_GO(true, 128, 128, 1);
+        static const int big_ku = getenv("SBL_BIG_KU") ? atoi(getenv("SBL_BIG_KU")) : 1;      // tuning knob
+        if (vec && big_ku == 2) SBL_GO(true, 128, 128, 2);
+        else if (vec) SBL_GO(true, 128, 128, 1);
         else SBL_GO(false, 128, 128, 1);
     } else {
         // KU = 4 (69 KB of LDS, 2 workgroups per CU) while every workgroup of the launch is resident at once; beyond
@@ -193,7 +195,7 @@ extern "C" int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda,
         K += seg_rows[t];
     }
     SBL_REQUIRE(K < (1L << 30), "sbl_wgrad_seg_f32: too many rows");
-    unsigned long long* stamp = sbl_next_stamp_slot(SBL_KID_TILED64);
+    unsigned long long* stamp = sbl_next_stamp_slot(SBL_KID_SEG_WGRAD);
     auto go = [&](auto al, auto tile_c, auto ku_c) {
         constexpr int T = decltype(tile_c)::value, KUc = decltype(ku_c)::value;
         decltype(al) bl;
