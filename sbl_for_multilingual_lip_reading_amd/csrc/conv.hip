@@ -124,16 +124,29 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     const int M = Cout, N = KH * KW * Cin, K = NIMG * Ho * Wo;   // reduce over output pixels
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * N, s));
-    // split the pixel reduction so that ~1024 workgroups are in flight; chunks stay >= 256 pixels
-    const long tiles = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    int splits = (int)((1024 + tiles - 1) / tiles);
-    if (splits > K / 256) splits = K / 256;
-    if (splits < 1) splits = 1;
-    DenseMC<64, true> al{dy, (long)Cout, M};
-    ConvGatherMC<64> bl{x, g, N};
-    EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};
+    // split the pixel reduction: 128x128 tiles for the 128+-channel layers (twice the flops per staged byte), 64x64
+    // otherwise, and 6 / 12 workgroups per CU so that the uneven last chunks and the atomic epilogues of one
+    // workgroup hide behind the others (measured, tools/bench_conv.py: 465/477/511/515 us -> 411/355/437/453 us for
+    // layers 1-4); chunks stay >= 256 pixels
+    static const int wg_tile = getenv("SBL_WGRAD_TILE") ? atoi(getenv("SBL_WGRAD_TILE")) : 0;     // A/B knobs
+    static const int wg_target_env = getenv("SBL_WGRAD_TARGET") ? atoi(getenv("SBL_WGRAD_TARGET")) : 0;
+    const bool big = wg_tile ? wg_tile == 128 : (M >= 128 && N >= 1152);
+    const int wg_target = wg_target_env ? wg_target_env : (big ? 1536 : 3072);
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_WGRAD)};
-    sbl_launch_gemm<DenseMC<64, true>, ConvGatherMC<64>, EpiStore<2, false>, 64, 64>(al, bl, e, M, N, K, splits, s, sc);
+#define SBL_CONV_WG(BM, BN)                                                                                   \
+    do {                                                                                                      \
+        const long tiles = (long)sbl_cdiv(M, BM) * sbl_cdiv(N, BN);                                           \
+        int splits = (int)((wg_target + tiles - 1) / tiles);                                                  \
+        if (splits > K / 256) splits = K / 256;                                                               \
+        if (splits < 1) splits = 1;                                                                           \
+        DenseMC<BM, true> al{dy, (long)Cout, M};                                                              \
+        ConvGatherMC<BN> bl{x, g, N};                                                                         \
+        EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
+        sbl_launch_gemm<DenseMC<BM, true>, ConvGatherMC<BN>, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s, sc); \
+    } while (0)
+    if (big && M >= 128) SBL_CONV_WG(128, 128);
+    else SBL_CONV_WG(64, 64);
+#undef SBL_CONV_WG
     SBL_LAUNCH_CHECK("sbl_conv2d_wgrad");
     return 0;
 }

@@ -117,6 +117,9 @@ def _xs_out(*ts):
 
 
 CONV_WGRAD_SIDE = os.environ.get("SBL_CONV_WGRAD_SIDE", "1") != "0"
+# the second stream also carries the merged decoder weight-gradient GEMMs during the frontend backward; only every
+# k-th trunk dW goes there so that neither stream becomes the longer one
+CONV_WGRAD_SIDE_EVERY = int(os.environ.get("SBL_CONV_WGRAD_SIDE_EVERY", "1"))
 _side_join = {"armed": False}
 
 
@@ -127,6 +130,7 @@ def _arm_side_join():
 
         def join():
             _side_join["armed"] = False
+            _side_join["n"] = 0
             cur = torch.cuda.current_stream()
             side = _side_streams.get(cur.device_index)
             if side is not None and side != cur:
@@ -1024,7 +1028,8 @@ class ConvBNFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
         gw = _gbuf(w)
-        if gw is not None and CONV_WGRAD_SIDE:
+        _side_join["n"] = _side_join.get("n", 0) + 1
+        if gw is not None and CONV_WGRAD_SIDE and (CONV_WGRAD_SIDE_EVERY <= 1 or _side_join["n"] % CONV_WGRAD_SIDE_EVERY == 0):
             # the weight gradient is off backward's dependency chain: with a persistent gradient buffer it is issued
             # on the second stream, where its workgroups fill the CUs that the chain's kernels (tile-count
             # quantisation: 522 workgroups on 256 CUs) leave idle; joined by an end-of-backward engine callback
