@@ -64,12 +64,14 @@ class FlatModel:
         self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self.ranges = {}
+        self.slots = []          # (parameter, offset, padded numel) in buffer order
         off = 0
         with torch.no_grad():
             for seg in self.SEGMENTS:
                 start = off
                 for p in by_seg[seg]:
                     n = p.numel()
+                    self.slots.append((p, off, pad(n)))
                     self.flat_param[off:off + n].copy_(p.data.reshape(-1))
                     p.data = self.flat_param[off:off + n].view(p.shape)
                     p.grad = self.flat_grad[off:off + n].view(p.shape)
@@ -82,6 +84,19 @@ class FlatModel:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def trainable_ranges(self):
+        """Maximal contiguous [a, b) ranges of the flat buffers whose parameters have requires_grad=True (the
+        reference's README stage 2 freezes the encoder and builds Adam over filter(requires_grad), SBL/train.py:75)."""
+        out = []
+        for p, off, n in self.slots:
+            if not p.requires_grad:
+                continue
+            if out and out[-1][1] == off:
+                out[-1][1] = off + n
+            else:
+                out.append([off, off + n])
+        return [(a, b) for a, b in out]
 
     def segment_grad(self, seg):
         a, b = self.ranges[seg]

@@ -51,10 +51,14 @@ class FusedAdam(object):
         self.flat.zero_grad()
 
     def step(self):
+        """One launch per maximal run of trainable parameters (one launch in all when nothing is frozen): like
+        Adam(filter(lambda p: p.requires_grad, model.parameters())) in SBL/train.py:75, frozen parameters and their
+        moments are left untouched."""
         g = self.param_groups[0]
         self.step_count += 1
-        self._ops.adam_step(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, g["lr"],
-                            g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        for a, b in self.flat.trainable_ranges():
+            self._ops.adam_step(self.flat.flat_param[a:b], self.flat.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
+                                g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

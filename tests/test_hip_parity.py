@@ -782,6 +782,37 @@ def test_fused_adam_training_steps_match_torch_adam(ops):
             assert num < 1e-2 * float(p1[n].norm()) + 1e-6, (n, num)
 
 
+def test_frozen_encoder_stage_is_honoured(ops):
+    """README stage 2 (SBL/README.md:56-66, transformer.py:15-16): encoder parameters get requires_grad=False and the
+    optimizer is built over filter(requires_grad).  The kernels may still write those gradients into the flat buffer;
+    FusedAdam must leave the frozen parameters (and their moments) untouched and update everything else."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    from sbl_for_multilingual_lip_reading_amd.transformer.optimizer import FusedAdam, TransformerOptimizer
+    B, T, H, W = 2, 4, 24, 24
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 52)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    m = build_model(1, 1).train()
+    for p in m.encoder.parameters():
+        p.requires_grad = False
+    flat = dp.FlatModel(m)
+    opt = TransformerOptimizer(FusedAdam(flat, betas=(0.9, 0.98), eps=1e-09), warmup_steps=2, k=0.5)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    for step in range(2):
+        random.seed(200 + step)
+        opt.zero_grad()
+        pl, gl, pr, gr = m(xd, ld, rd)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        opt.step()
+    a, b = flat.ranges["encoder."]
+    assert float(opt.optimizer.exp_avg[a:b].abs().max()) == 0.0 and float(opt.optimizer.exp_avg_sq[a:b].abs().max()) == 0.0
+    moved = {n: float((p.detach() - before[n]).abs().max()) for n, p in m.named_parameters()}
+    assert all(v == 0.0 for n, v in moved.items() if n.startswith("encoder."))
+    assert all(v > 0.0 for n, v in moved.items() if n.startswith("decoder.") and n.endswith("weight") and "w_ks" not in n)
+    assert moved["visual_frontend.frontend3D.0.weight"] > 0.0 and moved["visual_frontend.resnet18.layer4.1.conv2.weight"] > 0.0
+
+
 @pytest.mark.parametrize("tag", ["small", "full"])
 def test_recognize_golden(ops, tag):
     g = load_golden("recognize_%s.npz" % tag)
