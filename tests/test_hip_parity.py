@@ -679,6 +679,37 @@ def test_e2e_matches_oracle_other_seed(ops):
             assert maxdiff(p.grad, r) < 2e-3 * float(r.abs().max()) + 2e-6, n
 
 
+def test_config5_shape_matches_oracle(ops):
+    """BASELINE config 5 geometry (T = 64 frames of 112x112: 28x28 trunk maps, encoder / cross-attention length 64 =
+    the workgroup attention kernels' maximum) at B = 2 with 1+1 layers, forward + loss + backward against the CPU
+    oracle.  No fixture of the reference covers this size; the oracle is pinned by the fixtures at the other sizes."""
+    from oracle import sbl_oracle as O
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    B, T, H, W, ne, nd = 2, 64, 112, 112, 1, 1
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 23)
+    sd = O.make_state_dict(ne, nd, requires_grad=True)
+    random.seed(9)
+    coins = O.draw_coins()
+    ref = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins, ne, nd)
+    rloss = O.train_step_loss(ref)
+    rloss.backward()
+    m = build_model(ne, nd).train()
+    random.seed(9)
+    pl, gl, pr, gr = m(torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV))
+    loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+    loss.backward()
+    assert maxdiff(pl, ref["pred_l2r"]) < 1e-3 and maxdiff(pr, ref["pred_r2l"]) < 1e-3      # north-star bar
+    assert abs(loss.item() - rloss.item()) < 1e-3
+    # relative L2 per tensor: with 557 k ReLU pre-activations per FFN a unit sitting within rounding of zero can
+    # switch sides between two fp32 summation orders, which moves ONE row of dW1 / one column of dW2 by a finite
+    # amount (seen here: max-abs 1.7 % on one row, L2 unaffected); element-wise bounds are kept at the other sizes
+    for n, p in m.named_parameters():
+        if (n.startswith("decoder") or n.startswith("encoder")) and not n.endswith("w_ks.bias"):
+            r = sd[n].grad
+            rel = float((p.grad.detach().cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
+            assert rel < 5e-3, (n, rel)
+
+
 def test_flat_direct_accumulation_and_two_streams_match_plain_autograd(ops):
     """The throughput path (dp.FlatModel: kernels accumulate gradients straight into one flat buffer, the two
     decoder directions on two HIP streams, dropout fused into LayerNorm with p=0) must give the same numbers as
