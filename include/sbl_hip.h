@@ -68,6 +68,16 @@ int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lo
  * <= 16 entries (device pointers inside).  C and a_colsum are accumulated with float atomics (split-K). */
 int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda, const float* const* B_ptrs, long ldb,
                       const int* seg_rows, int M, int N, float* C, long ldc, float* a_colsum, sbl_stream_t stream);
+/* The same for MANY weights in one launch (all deferred decoder weights of a step): every 128x128 tile of every
+ * C_p (+)= sum_s A_{p,s}^T B_{p,s} is owned by one workgroup over the whole K = sum(seg_rows) (no split-K, no
+ * atomics on C: deterministic).  All problems share nseg / seg_rows (multiples of 16 rows); A_ptrs / B_ptrs are HOST
+ * arrays of nprob*nseg device pointers (problem-major); lda/ldb/M/N/C/ldc/colsum HOST arrays of nprob entries
+ * (colsum[p] may be NULL).  table: device scratch of sbl_wgrad_group_table_bytes(nprob) bytes (problem descriptors,
+ * written by the call on `stream`). */
+long sbl_wgrad_group_table_bytes(int nprob);
+int sbl_wgrad_group_f32(int nprob, int nseg, const int* seg_rows, const float* const* A_ptrs, const long* lda,
+                        const float* const* B_ptrs, const long* ldb, const int* M, const int* N, float* const* C,
+                        const long* ldc, float* const* colsum, void* table, long table_bytes, sbl_stream_t stream);
 /* out[n] (+)= sum_m X[m*ldx + n]   (bias gradients) */
 int sbl_colsum_f32(const float* X, long ldx, float* out, int M, int N, int accumulate, sbl_stream_t stream);
 

@@ -13,6 +13,7 @@ P, I, L, F, U64 = c_void_p, c_int, c_long, c_float, c_uint64
 SIGNATURES = {
     "sbl_gemm_f32": [I, I, I, I, I, P, L, P, L, P, L, P, I, P, L, I, P, P, L, P],
     "sbl_wgrad_seg_f32": [I, P, L, P, L, P, I, I, P, L, P, P],
+    "sbl_wgrad_group_f32": [I, I, P, P, P, P, P, P, P, P, P, P, P, L, P],
     "sbl_colsum_f32": [P, L, P, I, I, I, P],
     "sbl_stem_conv_fwd": [P, P, P, P, I, I, I, I, P],
     "sbl_stem_bn_relu_pool_fwd": [P, P, P, P, P, P, P, I, I, I, P],
@@ -83,6 +84,8 @@ def load():
         getattr(lib, name).argtypes = []
     lib.sbl_profile_begin.restype = c_int
     lib.sbl_profile_begin.argtypes = [c_void_p, c_int]
+    lib.sbl_wgrad_group_table_bytes.restype = ctypes.c_long
+    lib.sbl_wgrad_group_table_bytes.argtypes = [c_int]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
         fn.restype = c_int

@@ -230,6 +230,118 @@ extern "C" int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda,
     return 0;
 }
 
+// ------------------------------------------------------------------ all deferred weight gradients in ONE launch
+// The per-weight launches above have 16-64 output tiles each, so they split K 12-24 ways to fill the chip: short K
+// loops, and every output element is hit by that many float atomics.  All weights of a step share the same stage row
+// structure, so they can be one grouped launch: 2688 128x128 tiles for the 72 decoder weights, each tile owned by one
+// workgroup over the whole K = 4352 (a long, efficient K loop), C += acc without atomics (deterministic), ~10 tiles
+// per CU for balance.  Problem descriptors live in a device table written by a tiny kernel (they do not fit in 4 KB
+// of kernel arguments, and a host->device copy cannot be captured into a hipGraph from pageable memory).
+struct GroupProb {
+    const float* a[SBL_MAX_KSEG];
+    const float* b[SBL_MAX_KSEG];
+    float* C;
+    float* colsum;
+    long lda, ldb, ldc;
+    int M, N, tile0, tiles_m;
+};
+#define SBL_GROUP_WRITE 8
+struct GroupWrite {
+    GroupProb p[SBL_GROUP_WRITE];
+};
+__global__ void group_write_kernel(GroupWrite w, GroupProb* table, int first, int count) {
+    const int i = threadIdx.x;
+    if (i < count) table[first + i] = w.p[i];
+}
+struct GroupCommon {
+    int nprob, nseg, K;
+    int kcum[SBL_MAX_KSEG + 1];
+};
+__global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* __restrict__ table, GroupCommon gc,
+                                                              unsigned long long* stamp) {
+    // problem of this tile: binary search over tile0 (ascending), workgroup-uniform
+    int lo = 0, hi = gc.nprob - 1;
+    const int t = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    const GroupProb& g = table[lo];
+    const int lt = t - g.tile0;
+    const int tx = lt % g.tiles_m, ty = lt / g.tiles_m;
+    SegMC<128, true> al, bl;
+#pragma unroll
+    for (int s = 0; s < SBL_MAX_KSEG; ++s) {
+        al.p[s] = g.a[s];
+        bl.p[s] = g.b[s];
+        al.kcum[s] = bl.kcum[s] = gc.kcum[s];
+    }
+    al.kcum[SBL_MAX_KSEG] = bl.kcum[SBL_MAX_KSEG] = gc.K;
+    al.nseg = bl.nseg = gc.nseg;
+    al.ld = g.lda; bl.ld = g.ldb;
+    al.rows = g.M; bl.rows = g.N;
+    EpiStore<1, false> e{g.C, g.ldc, nullptr, 0, nullptr, nullptr, 0};
+    SplitCtl sc{nullptr, nullptr, g.colsum, stamp};
+    sbl_gemm_tile<SegMC<128, true>, SegMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2>(al, bl, e, sc, g.M, g.N, tx * 128, ty * 128, 0,
+                                                                                        gc.K, 0, 0, 1, ty == 0);
+}
+
+extern "C" long sbl_wgrad_group_table_bytes(int nprob) { return (long)sizeof(GroupProb) * (nprob > 0 ? nprob : 0); }
+
+extern "C" int sbl_wgrad_group_f32(int nprob, int nseg, const int* seg_rows, const float* const* A_ptrs, const long* lda,
+                                   const float* const* B_ptrs, const long* ldb, const int* M, const int* N, float* const* C,
+                                   const long* ldc, float* const* colsum, void* table, long table_bytes,
+                                   sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(nprob >= 1 && nprob <= 4096 && nseg >= 1 && nseg <= SBL_MAX_KSEG && seg_rows && A_ptrs && B_ptrs && lda && ldb && M && N && C && ldc && colsum,
+                "sbl_wgrad_group_f32: bad arguments (nprob=%d nseg=%d)", nprob, nseg);
+    SBL_REQUIRE(table && sbl_aligned16(table) && table_bytes >= sbl_wgrad_group_table_bytes(nprob), "sbl_wgrad_group_f32: descriptor table too small");
+    GroupCommon gc;
+    gc.nprob = nprob;
+    gc.nseg = nseg;
+    long K = 0;
+    for (int t = 0; t < SBL_MAX_KSEG; ++t) {
+        gc.kcum[t] = (int)K;
+        if (t < nseg) {
+            SBL_REQUIRE(seg_rows[t] > 0 && seg_rows[t] % SBL_BK == 0, "sbl_wgrad_group_f32: segment %d has %d rows (must be a positive multiple of %d)", t, seg_rows[t], SBL_BK);
+            K += seg_rows[t];
+        }
+    }
+    SBL_REQUIRE(K < (1L << 30), "sbl_wgrad_group_f32: too many rows");
+    gc.kcum[SBL_MAX_KSEG] = (int)K;
+    gc.K = (int)K;
+    long tiles = 0;
+    GroupProb* tab = (GroupProb*)table;
+    for (int first = 0; first < nprob; first += SBL_GROUP_WRITE) {
+        GroupWrite w;
+        const int count = nprob - first < SBL_GROUP_WRITE ? nprob - first : SBL_GROUP_WRITE;
+        for (int i = 0; i < count; ++i) {
+            const int p = first + i;
+            GroupProb& g = w.p[i];
+            SBL_REQUIRE(M[p] > 0 && N[p] > 0 && C[p] && lda[p] >= M[p] && ldb[p] >= N[p] && ldc[p] >= N[p] && lda[p] % 4 == 0 && ldb[p] % 4 == 0,
+                        "sbl_wgrad_group_f32: problem %d has bad dims M=%d N=%d lda=%ld ldb=%ld ldc=%ld", p, M[p], N[p], lda[p], ldb[p], ldc[p]);
+            for (int t = 0; t < SBL_MAX_KSEG; ++t) {
+                g.a[t] = t < nseg ? A_ptrs[(long)p * nseg + t] : nullptr;
+                g.b[t] = t < nseg ? B_ptrs[(long)p * nseg + t] : nullptr;
+                SBL_REQUIRE(t >= nseg || (g.a[t] && g.b[t] && sbl_aligned16(g.a[t]) && sbl_aligned16(g.b[t])), "sbl_wgrad_group_f32: problem %d segment %d null/unaligned", p, t);
+            }
+            g.C = C[p];
+            g.colsum = colsum[p];
+            g.lda = lda[p]; g.ldb = ldb[p]; g.ldc = ldc[p];
+            g.M = M[p]; g.N = N[p];
+            g.tile0 = (int)tiles;
+            g.tiles_m = sbl_cdiv(M[p], 128);
+            tiles += (long)g.tiles_m * sbl_cdiv(N[p], 128);
+        }
+        hipLaunchKernelGGL(group_write_kernel, dim3(1), dim3(64), 0, s, w, tab, first, count);
+    }
+    SBL_REQUIRE(tiles < (1L << 30), "sbl_wgrad_group_f32: too many tiles");
+    hipLaunchKernelGGL(sbl_wgrad_group_kernel, dim3((unsigned)tiles), dim3(256), 0, s, (const GroupProb*)tab, gc,
+                       sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
+    SBL_LAUNCH_CHECK("sbl_wgrad_group_f32");
+    return 0;
+}
+
 // ------------------------------------------------------------------ column sums (bias grads)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ldx, float* __restrict__ out,
                                                      int M, int N, int rows_per_block) {

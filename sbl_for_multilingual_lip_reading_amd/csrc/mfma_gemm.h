@@ -481,9 +481,12 @@ struct SplitCtl {
 // step: 4x the bytes in flight per step, 4x fewer exposed latencies and barriers.
 // WN = wavefronts along N (2: the 2x2 layout; 1: four wavefronts stacked along M, e.g. a 256x64 tile whose waves
 // each own 64x64 = the LDS-read intensity of a 128x128 tile for the 64-channel layers).
-template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2>
-__global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
-                                                            int kchunk) {
+// The body of one workgroup: output tile at (m0, n0), K range [kbeg, kend); (tile, z, nz) identify the split-K
+// slice for the in-launch slab reduction (nz == 1: no split), colsum_tile: this workgroup feeds a_colsum.
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN>
+__device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
+                                              int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
+                                              bool colsum_tile) {
     constexpr int MK = KU * SBL_BK;   // macro step
     __shared__ __attribute__((aligned(16))) float As[2][MK][BM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][MK][BN + 4];
@@ -492,9 +495,6 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * kchunk;
-    const int kend = min(K, kbeg + kchunk);
     sbl_stamp_begin(sc.stamp);
 
     typename AL::State sa;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     typename BL::Regs rb[KU];
     al.init(sa, m0, tid);
     bl.init(sb, n0, tid);
-    const bool do_colsum = AL::kColSum && sc.a_colsum != nullptr && blockIdx.y == 0;
+    const bool do_colsum = AL::kColSum && sc.a_colsum != nullptr && colsum_tile;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
     f32x16 acc[TM][TN];
@@ -587,10 +587,8 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     }
 
     // in-launch split-K reduction (last-arriving workgroup of each tile)
-    if (gridDim.z > 1 && sc.slabs != nullptr) {
-        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-        const int nz = gridDim.z;
-        float* mine = sc.slabs + ((long)tile * nz + blockIdx.z) * (BM * BN);
+    if (nz > 1 && sc.slabs != nullptr) {
+        float* mine = sc.slabs + ((long)tile * nz + z) * (BM * BN);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -651,6 +649,14 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
         }
     }
     sbl_stamp_end(sc.stamp);
+}
+
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2>
+__global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
+                                                            int kchunk) {
+    const int kbeg = blockIdx.z * kchunk;
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, blockIdx.x * BM, blockIdx.y * BN, kbeg, min(K, kbeg + kchunk),
+                                               blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, gridDim.z, blockIdx.y == 0);
 }
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>

@@ -206,18 +206,41 @@ class WgradCollector:
                 side.wait_stream(cur)
                 run = side
         with torch.cuda.stream(run):
+            # weights whose stages have the same row structure (all layer weights of both directions) form one group
+            groups = {}
             for e in self.entries.values():
-                n = len(e["rows"])
-                for i in range(0, n, 16):
-                    A, B, rows = e["A"][i:i + 16], e["B"][i:i + 16], e["rows"][i:i + 16]
-                    k = len(rows)
-                    pa = (_ct.c_void_p * k)(*[t.data_ptr() for t in A])
-                    pb = (_ct.c_void_p * k)(*[t.data_ptr() for t in B])
-                    pr = (_ct.c_int * k)(*rows)
-                    call("sbl_wgrad_seg_f32", k, pa, e["lda"], pb, e["ldb"], pr, e["M"], e["N"], _p(e["C"]), e["ldc"],
-                         _p(e["colsum"]), _s())
-                for t in e["A"] + e["B"]:
-                    t.record_stream(run)
+                groups.setdefault(tuple(e["rows"]), []).append(e)
+            for rows0, ents in groups.items():
+                grouped = GROUP_WGRAD and len(ents) > 1 and len(rows0) <= 16 and all(r % 16 == 0 for r in rows0)
+                if grouped:
+                    # one launch for every weight: each 128x128 tile of each gradient is owned by one workgroup over
+                    # the whole K = all stages' rows (no split-K, no atomics; see sbl_wgrad_group_f32)
+                    n, k = len(ents), len(rows0)
+                    need = _lib.load().sbl_wgrad_group_table_bytes(n)
+                    key = (run.device_index, run.cuda_stream, len(groups) > 1 and rows0)
+                    tab = _group_tables.get(key)
+                    if tab is None or tab.numel() < need:
+                        tab = _group_tables[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=torch.device("cuda", run.device_index))
+                    pa = (_ct.c_void_p * (n * k))(*[t.data_ptr() for e in ents for t in e["A"]])
+                    pb = (_ct.c_void_p * (n * k))(*[t.data_ptr() for e in ents for t in e["B"]])
+                    call("sbl_wgrad_group_f32", n, k, (_ct.c_int * k)(*rows0), pa, (_ct.c_long * n)(*[e["lda"] for e in ents]), pb,
+                         (_ct.c_long * n)(*[e["ldb"] for e in ents]), (_ct.c_int * n)(*[e["M"] for e in ents]),
+                         (_ct.c_int * n)(*[e["N"] for e in ents]), (_ct.c_void_p * n)(*[e["C"].data_ptr() for e in ents]),
+                         (_ct.c_long * n)(*[e["ldc"] for e in ents]), (_ct.c_void_p * n)(*[_p(e["colsum"]) for e in ents]),
+                         tab.data_ptr(), tab.numel(), _s())
+                for e in ents:
+                    if not grouped:
+                        n = len(e["rows"])
+                        for i in range(0, n, 16):
+                            A, B, rows = e["A"][i:i + 16], e["B"][i:i + 16], e["rows"][i:i + 16]
+                            k = len(rows)
+                            pa = (_ct.c_void_p * k)(*[t.data_ptr() for t in A])
+                            pb = (_ct.c_void_p * k)(*[t.data_ptr() for t in B])
+                            pr = (_ct.c_int * k)(*rows)
+                            call("sbl_wgrad_seg_f32", k, pa, e["lda"], pb, e["ldb"], pr, e["M"], e["N"], _p(e["C"]), e["ldc"],
+                                 _p(e["colsum"]), _s())
+                    for t in e["A"] + e["B"]:
+                        t.record_stream(run)
         self.entries = {}
         self.flushes += 1
 
@@ -234,6 +257,8 @@ class WgradCollector:
 
 
 FLUSH_ON_SIDE = os.environ.get("SBL_FLUSH_ON_SIDE", "1") != "0"
+GROUP_WGRAD = os.environ.get("SBL_GROUP_WGRAD", "1") != "0"
+_group_tables = {}
 _armed = []
 
 
