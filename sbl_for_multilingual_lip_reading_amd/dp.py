@@ -150,8 +150,9 @@ class GradientExchange:
         g = self.flat.segment_grad(seg)
         if self.cuda:
             cur = torch.cuda.current_stream()
-            if seg == "decoder.":
-                _ops().flush_deferred()       # the decoder's merged weight-gradient GEMMs must be issued first
+            # the finished segment's merged weight-gradient GEMMs (decoder and encoder layers defer theirs) must be
+            # issued before its all-reduce; idempotent
+            _ops().flush_deferred()
             side = _ops()._side_streams.get(cur.device_index)
             if side is not None:
                 self.stream.wait_stream(side)

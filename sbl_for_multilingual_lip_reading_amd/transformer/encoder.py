@@ -1,4 +1,5 @@
 """Mirror of SBL_Multilingual_Lip_reading/transformer/encoder.py."""
+import torch
 import torch.nn as nn
 
 from ._env import ops
@@ -50,6 +51,13 @@ class Encoder(nn.Module):
             non_pad_mask = get_non_pad_mask(padded_input, input_lengths=input_lengths)
             slf_attn_mask = get_attn_pad_mask(padded_input, input_lengths, T)
 
+        # the layers' weight gradients are deferred and issued as one grouped launch when backward reaches the
+        # encoder input (second stream, under the frontend backward) or at the end of backward, whichever is first
+        defer = torch.is_grad_enabled()
+        if defer:
+            ops.begin_defer()
+            if padded_input.requires_grad:
+                padded_input.register_hook(lambda g: ops.flush_deferred())
         # dropout(LayerNorm(linear_in(x)) + pe[:T])  (encoder.py:53-55)
         h = ops.linear(padded_input, self.linear_in.weight, self.linear_in.bias)
         h = ops.add_layernorm(h, None, self.layer_norm_in.weight, self.layer_norm_in.bias, self.layer_norm_in.eps)
@@ -64,6 +72,8 @@ class Encoder(nn.Module):
             if return_attns:
                 enc_slf_attn_list += [enc_slf_attn]
 
+        if defer:
+            ops.end_defer()
         if return_attns:
             return enc_output, enc_slf_attn_list
         return enc_output,

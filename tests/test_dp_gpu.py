@@ -66,7 +66,18 @@ def test_two_ranks_exchange_equals_mean_of_shard_gradients(tmp_path):
     procs = [ctx.Process(target=_worker, args=(r, 2, 29641, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
-    paths = dict(q.get(timeout=600) for _ in procs)
+    paths = {}
+    import queue as _queue
+    import time as _time
+    t_end = _time.time() + 300
+    while len(paths) < len(procs):                      # fail fast if a rank dies instead of waiting out the timeout
+        try:
+            r, pth = q.get(timeout=2)
+            paths[r] = pth
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, "a rank exited with %s" % dead
+            assert _time.time() < t_end, "ranks did not finish in time"
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
