@@ -45,7 +45,7 @@ KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW,
                 4: "sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (trunk conv fwd + BN stats)",
                 5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
                 6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)",
-                7: "sbl_mfma_gemm_kernel<SegMC,SegMC> (decoder weight grads merged over all stages, split-K atomics)"}
+                7: "sbl_wgrad_group_kernel<SegMC,SegMC 128x128> (all deferred decoder / encoder weight grads, one launch each, no split-K)"}
 T_START = time.perf_counter()
 
 
@@ -106,12 +106,15 @@ class LaunchRecorder:
         def call(name, *a):
             if not self.active:
                 return inner(name, *a)
-            s0 = self.lib.sbl_profile_last_slot()
+            s0 = self.lib.sbl_profile_used()       # process-wide counter: backward runs on the autograd thread
             inner(name, *a)
             if name == "sbl_gemm_f32":
                 fl = 2.0 * a[2] * a[3] * a[4]
             elif name == "sbl_wgrad_seg_f32":      # merged decoder weight gradient: contracts over all stages' rows
                 fl = 2.0 * a[6] * a[7] * sum(a[5][i] for i in range(a[0]))
+            elif name == "sbl_wgrad_group_f32":    # every deferred weight gradient in one launch
+                rows = sum(a[2][i] for i in range(a[1]))
+                fl = sum(2.0 * a[7][p] * a[8][p] * rows for p in range(a[0]))
             elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_wgrad"):
                 off = 1 if name == "sbl_conv2d_fwd" else 0
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
@@ -119,9 +122,9 @@ class LaunchRecorder:
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
             else:
                 return
-            s1 = self.lib.sbl_profile_last_slot()
+            s1 = self.lib.sbl_profile_used()
             if s1 > s0:      # a call may make several launches (stride-2 input gradients: one per parity class)
-                self.launches.append((tuple(range(s0 + 1, s1 + 1)), self.lib.sbl_profile_last_kernel(), fl))
+                self.launches.append((tuple(range(s0, s1)), self.lib.sbl_profile_last_kernel(), fl))
         ops.call = call
 
 

@@ -39,9 +39,12 @@ int sbl_abi_version(void);
  * stamps[2*slot] = min start, stamps[2*slot+1] = max end of its workgroups, in 100 MHz s_memrealtime ticks
  * (caller pre-fills starts with ~0 and ends with 0).  The slot pointer is baked into the launch, so stamps are
  * taken inside hipGraph replays too.  sbl_profile_last_slot/kernel report the launch just enqueued by this thread
- * (slot -1 = not instrumented; kernel 1 skinny GEMM, 2 tiled 64x64, 3 tiled 128x128, 4/5/6 conv fwd/dgrad/wgrad). */
+ * (slot -1 = not instrumented; kernel 1 skinny GEMM, 2 tiled 64x64, 3 tiled 128x128, 4/5/6 conv fwd/dgrad/wgrad,
+ * 7 merged decoder/encoder weight gradients); sbl_profile_used = slots handed out so far by ALL threads (autograd
+ * runs backward on its own thread, so a caller brackets a call with it to learn which slots the call used). */
 int sbl_profile_begin(uint64_t* stamps, int capacity);
 int sbl_profile_end(void);
+int sbl_profile_used(void);
 int sbl_profile_last_slot(void);
 int sbl_profile_last_kernel(void);
 

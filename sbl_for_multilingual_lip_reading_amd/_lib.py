@@ -79,7 +79,7 @@ def load():
     lib.sbl_last_error.argtypes = []
     lib.sbl_abi_version.restype = c_int
     lib.sbl_abi_version.argtypes = []
-    for name in ("sbl_profile_end", "sbl_profile_last_slot", "sbl_profile_last_kernel"):
+    for name in ("sbl_profile_end", "sbl_profile_last_slot", "sbl_profile_last_kernel", "sbl_profile_used"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = []
     lib.sbl_profile_begin.restype = c_int

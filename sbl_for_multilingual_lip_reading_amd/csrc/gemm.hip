@@ -41,6 +41,7 @@ extern "C" int sbl_profile_end(void) {
     return used;
 }
 extern "C" int sbl_profile_last_slot(void) { return g_last_slot; }
+extern "C" int sbl_profile_used(void) { return g_stamp_used; }      // process-wide (last_slot is per calling thread)
 extern "C" int sbl_profile_last_kernel(void) { return g_last_kid; }
 extern "C" int sbl_abi_version(void) { return SBL_ABI_VERSION; }
 

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # ctypes table == header (minus the two non-int helpers)
     helpers = ("sbl_last_error", "sbl_abi_version", "sbl_profile_begin", "sbl_profile_end", "sbl_profile_last_slot",
-               "sbl_profile_last_kernel", "sbl_wgrad_group_table_bytes")      # bound by hand in _lib.load()
+               "sbl_profile_last_kernel", "sbl_profile_used", "sbl_wgrad_group_table_bytes")      # bound by hand in _lib.load()
     assert sorted(_lib.SIGNATURES) == sorted(n for n in names if n not in helpers)
     for h in helpers:
         assert hasattr(lib, h)
