@@ -380,7 +380,12 @@ __global__ __launch_bounds__(256) void attention_small_fwd_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void attention_small_bwd_kernel(const float* __restrict__ dout, long lddo, const float* __restrict__ q,
+// SHARED_KV: cross-attention of a run with several segments.  All segments of one (batch, head) share the key /
+// value rows, so they are the wavefronts of ONE workgroup (blockDim = 64 * nseg, grid = B * H): each adds its dK / dV
+// tile into a 16 KB LDS image (ds_add_f32) and the workgroup stores the sums with plain 16-byte stores - no global
+// atomics (they cost 33 / 70 us per launch at 2 / 5 segments against 12 us for one), no zero-filled output.
+template <bool SHARED_KV>
+__global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_kernel(const float* __restrict__ dout, long lddo, const float* __restrict__ q,
                                                                   long ldq, const float* __restrict__ k, long ldk,
                                                                   const float* __restrict__ v, long ldv, const float* __restrict__ p,
                                                                   float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
@@ -388,8 +393,10 @@ __global__ __launch_bounds__(256) void attention_small_bwd_kernel(const float* _
                                                                   int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
                                                                   const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    const int prob = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (prob >= nprob) return;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // SHARED_KV: [segment][dV | dK][32][64] partial tiles
+    float* s_kv = s_dyn + (threadIdx.x >> 6) * 4096;                    // this wavefront's slice
+    const int prob = SHARED_KV ? (int)(threadIdx.x >> 6) * (B * H) + (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (!SHARED_KV && prob >= nprob) return;
     const SmallProb P = small_prob(prob, B, H, segs, Lk_fixed);
     const int Lq = P.Lq, Lk = P.Lk;
     const int NT = Lk > 16 ? 2 : 1;
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(256) void attention_small_bwd_kernel(const float* _
     const float* gb = dout + P.qrow * lddo + P.h * 64;
     const float* pg = p + P.pbase;
     const uint64_t sd = thresh ? *seed : 0;
-    const bool kv_atomic = Lk_fixed > 0 && segs.nseg > 1;
+    const bool kv_atomic = !SHARED_KV && Lk_fixed > 0 && segs.nseg > 1;
     RowFrag gf;   // dO rows on n
     frag_load(gf, gb, lddo, n, n < Lq, g);
     // ---- pass T: dP and P in the T layout (i = n, j = 16t + 4g + r)  ->  dS_T, then dQ = dS K
@@ -533,7 +540,10 @@ __global__ __launch_bounds__(256) void attention_small_bwd_kernel(const float* _
                 if (j < Lk) {
                     float* pv_ = dvb + (long)j * lddv + 4 * n;
                     float* pk_ = dkb + (long)j * lddk + 4 * n;
-                    if (kv_atomic) {
+                    if (SHARED_KV) {      // (LDS float atomics into one shared image were measured 20 us slower at 5 segments)
+                        *reinterpret_cast<float4*>(&s_kv[j * 64 + 4 * n]) = make_float4(av[0][r], av[1][r], av[2][r], av[3][r]);
+                        *reinterpret_cast<float4*>(&s_kv[2048 + j * 64 + 4 * n]) = make_float4(ak[0][r], ak[1][r], ak[2][r], ak[3][r]);
+                    } else if (kv_atomic) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             atomicAdd(pv_ + e, av[e][r]);
@@ -545,6 +555,21 @@ __global__ __launch_bounds__(256) void attention_small_bwd_kernel(const float* _
                     }
                 }
             }
+        }
+    }
+    if (SHARED_KV) {
+        __syncthreads();
+        const int nw = blockDim.x >> 6;
+        for (int i = threadIdx.x; i < 2 * Lk * 16; i += blockDim.x) {
+            const int which = i / (Lk * 16), rem = i - which * (Lk * 16);
+            const int j = rem >> 4, c = (rem & 15) * 4;
+            float4 val = *reinterpret_cast<const float4*>(&s_dyn[which * 2048 + j * 64 + c]);
+            for (int w = 1; w < nw; ++w) {      // segment order: deterministic
+                const float4 u = *reinterpret_cast<const float4*>(&s_dyn[w * 4096 + which * 2048 + j * 64 + c]);
+                val.x += u.x; val.y += u.y; val.z += u.z; val.w += u.w;
+            }
+            float* dst = which ? dkb + (long)j * lddk + c : dvb + (long)j * lddv + c;
+            *reinterpret_cast<float4*>(dst) = val;
         }
     }
 }
@@ -580,8 +605,9 @@ static int at_attr(const void* fn, size_t lds, bool* flags) {
 // Segmented form: seg_L = host array of nseg prefix lengths (1..16 entries).  Lk_fixed == 0: self-attention inside
 // each segment (q/k/v rows of segment s start at sum_{t<s} B*seg_L[t]); Lk_fixed > 0: every segment's queries attend
 // to the same (B, Lk_fixed) key/value rows (decoder cross-attention).  p_out holds the segments' probability
-// blocks back to back, each (H*B, L, Lk).  In backward with shared keys and nseg > 1, dk/dv must be zeroed by the
-// caller (contributions are atomically accumulated).
+// blocks back to back, each (H*B, L, Lk).  In backward dq / dk / dv are always overwritten (with shared keys and
+// several segments the contributions are summed in LDS by one workgroup per (batch, head), or, beyond 8 segments /
+// 16 queries, accumulated with float atomics into a buffer the call zero-fills itself).
 extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* o,
                                      long ldo, float* p_out, int mask_kind, const uint8_t* mask, int B, int H,
                                      const int* seg_L, int nseg, int Lk_fixed, float scale, float drop_p,
@@ -626,11 +652,29 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
     if (at_small_ok(d, Lk_fixed, 0) && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && sbl_aligned16(dq) && sbl_aligned16(dk) &&
         sbl_aligned16(dv)) {
         const int nprob = nseg * B * H;
-        hipLaunchKernelGGL(attention_small_bwd_kernel, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, dout, lddo, q, ldq,
-                           k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
-                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+        static const int shared_kv = getenv("SBL_ATT_SHARED_KV") ? atoi(getenv("SBL_ATT_SHARED_KV")) : 1;   // A/B knob
+        if (Lk_fixed > 0 && nseg > 1 && !(shared_kv && nseg <= 8)) {      // atomics path accumulates: start from zero
+            SBL_HIP(hipMemset2DAsync(dk, lddk * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
+            SBL_HIP(hipMemset2DAsync(dv, lddv * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
+        }
+        if (shared_kv && Lk_fixed > 0 && nseg > 1 && nseg <= 8) {     // 8 wavefronts = 2 per SIMD at this kernel's register use
+            static bool attr_set2[64] = {false};
+            if (int e = at_attr((const void*)attention_small_bwd_kernel<true>, 8 * 16384, attr_set2)) return e;
+        }
+        if (shared_kv && Lk_fixed > 0 && nseg > 1 && nseg <= 8)
+            hipLaunchKernelGGL(attention_small_bwd_kernel<true>, dim3(B * H), dim3(64 * nseg), (size_t)nseg * 16384, (hipStream_t)stream, dout, lddo, q,
+                               ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
+                               drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+        else
+            hipLaunchKernelGGL(attention_small_bwd_kernel<false>, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, dout,
+                               lddo, q, ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
+                               drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
         SBL_LAUNCH_CHECK("sbl_attention_bwd(small)");
         return 0;
+    }
+    if (Lk_fixed > 0 && nseg > 1) {      // shared keys: the workgroup kernel accumulates dK / dV with float atomics
+        SBL_HIP(hipMemset2DAsync(dk, lddk * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
+        SBL_HIP(hipMemset2DAsync(dv, lddv * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
     }
     const size_t lds = sizeof(float) * 6 * AT_SZ;
     static bool attr_set[64] = {false};

@@ -745,8 +745,8 @@ class MHAFn(torch.autograd.Function):
             _xs_out(dx)
             return (dx, None) + wret + (dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret) + (None,) * 7
         dq = torch.empty(M, HD, device=dev, dtype=torch.float32)
-        # several segments share the keys/values: their dK/dV contributions are atomically accumulated
-        dkv = (torch.zeros if nseg > 1 else torch.empty)(B * Lk, 2 * HD, device=dev, dtype=torch.float32)
+        # several segments share the keys/values: their dK/dV contributions are summed inside the call
+        dkv = torch.empty(B * Lk, 2 * HD, device=dev, dtype=torch.float32)
         call("sbl_attention_seg_bwd", _p(datt), HD, _p(qkv), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(p), _p(dq), HD,
              _p(dkv), 2 * HD, _p(dkv[:, HD:]), 2 * HD, B, H, seg_arr, nseg, Lk, 1.0 / 8.0, drop_p, _p(seed), off_a, _s())
         dwq, acc, dwq_ret = _target(g_qkv[0], (HD, D), dev)

@@ -485,9 +485,8 @@ def _seg_attention_bwd(ops, do, q, k, v, p, B, H, segL, Lk_fixed, drop_p, seed, 
     arr = (ctypes.c_int * len(segL))(*segL)
     HD = H * 64
     dq = torch.empty_like(q)
-    shared = Lk_fixed > 0 and len(segL) > 1
-    dk = torch.zeros_like(k) if shared else torch.empty_like(k)
-    dv = torch.zeros_like(v) if shared else torch.empty_like(v)
+    dk = torch.full_like(k, 7.0)      # the call overwrites (it sums shared-key contributions itself)
+    dv = torch.full_like(v, 7.0)
     ops.call("sbl_attention_seg_bwd", do.data_ptr(), HD, q.data_ptr(), HD, k.data_ptr(), HD, v.data_ptr(), HD, p.data_ptr(),
              dq.data_ptr(), HD, dk.data_ptr(), HD, dv.data_ptr(), HD, B, H, arr, len(segL), Lk_fixed, 0.125, drop_p,
              seed.data_ptr() if drop_p else None, offset, ops._s())
@@ -495,7 +494,8 @@ def _seg_attention_bwd(ops, do, q, k, v, p, B, H, segL, Lk_fixed, drop_p, seed, 
 
 
 @pytest.mark.parametrize("segL,Lk_fixed,causal", [((3, 16, 9), 0, True), ((1, 2), 0, False), ((5, 16, 7, 1), 29, False),
-                                                  ((16,), 32, False), ((4,), 13, False), ((12, 20), 29, False)])
+                                                  ((16,), 32, False), ((4,), 13, False), ((12, 20), 29, False),
+                                                  ((1, 2, 3, 4, 5, 6, 7, 8, 9, 10), 29, False)])
 def test_segmented_attention_decoder_sizes(ops, segL, Lk_fixed, causal):
     """The ragged attention entry points at decoder sizes (<= 16 queries, <= 32 keys take the one-wavefront-per-problem
     kernels; the (12, 20) case the workgroup kernel) against fp64 torch, forward and backward, plus the dropout path
