@@ -258,6 +258,7 @@ class WgradCollector:
 
 FLUSH_ON_SIDE = os.environ.get("SBL_FLUSH_ON_SIDE", "1") != "0"
 GROUP_WGRAD = os.environ.get("SBL_GROUP_WGRAD", "1") != "0"
+FLUSH_AT_DECODER_END = os.environ.get("SBL_FLUSH_AT_DECODER_END", "1") == "1"
 _group_tables = {}
 _armed = []
 
