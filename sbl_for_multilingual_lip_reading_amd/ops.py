@@ -1006,7 +1006,9 @@ class ConvBNFn(torch.autograd.Function):
         Wo = (W + 2 * pad - KW) // stride + 1
         dev = x.device
         w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
-        call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), None, Cout, Cin, KH, KW, _s())
+        # the input-gradient layout [Cin][kh][kw][Cout] is packed by the same launch and kept for backward
+        w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if (training and x.requires_grad and torch.is_grad_enabled()) else None
+        call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
         conv = torch.empty(NIMG, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         mean = torch.empty(Cout, device=dev, dtype=torch.float32)
         invstd = torch.empty(Cout, device=dev, dtype=torch.float32)
@@ -1022,13 +1024,13 @@ class ConvBNFn(torch.autograd.Function):
         r = None if res is None else res.contiguous()
         call("sbl_bn_apply_fwd", _p(conv), _p(r), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), NIMG * Ho * Wo, Cout,
              int(relu), _s())
-        ctx.save_for_backward(x, w, conv, y if relu else None, mean, invstd, gamma)
+        ctx.save_for_backward(x, w, conv, y if relu else None, mean, invstd, gamma, w_dg)
         ctx.cfg = (relu, stride, pad, training, res is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, conv, y, mean, invstd, gamma = ctx.saved_tensors
+        x, w, conv, y, mean, invstd, gamma, w_dg = ctx.saved_tensors
         relu, stride, pad, training, has_res = ctx.cfg
         if not training:
             raise _lib.SblHipError("ConvBN backward is implemented for training-mode BatchNorm only")
@@ -1048,9 +1050,10 @@ class ConvBNFn(torch.autograd.Function):
              _p(dgamma), _p(dbeta), rows, Cout, int(relu), _s())
         dx = None
         if ctx.needs_input_grad[0]:
-            w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
-            w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
-            call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
+            if w_dg is None:
+                w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+                w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
+                call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
             dx = torch.empty_like(x)
             call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
         gw = _gbuf(w)
