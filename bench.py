@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--per-step-decoder", action="store_true", help="one decoder stage per step (no run batching)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-stream", action="store_true", help="run the two decoder directions on one stream")
+    ap.add_argument("--split-graph", choices=("auto", "on", "off"), default="auto",
+                    help="capture the step as two hipGraphs (everything up to the encoder's input gradient | frontend backward) so "
+                         "that the decoder + encoder gradient all-reduces overlap the frontend backward; auto = on when N > 1")
     ap.add_argument("--hang-dump", type=int, default=0, help="debug: dump all Python stacks after this many seconds")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args()
@@ -223,6 +226,31 @@ def main():
         ops.join_side_streams()          # the decoder's second stream rejoins before the step ends
         loss_out.copy_(loss.detach())
 
+    # The same step in two parts (Transformer.forward, transformer.py:27-36, with the tape cut at the frontend features):
+    # part A = forward + loss + backward of decoder and encoder, leaving d(loss)/d(features) in feats_d.grad;
+    # part B = backward of the visual frontend.  Between them the decoder / encoder gradient segments are complete,
+    # so their all-reduces run beside part B (overlap the exchange with the frontend backward).
+    split = {}
+
+    def part_a():
+        drop.begin_step()
+        flat.zero_grad()
+        feats = model.visual_frontend(x.unsqueeze(4).permute(0, 4, 1, 2, 3))
+        feats_d = feats.detach().requires_grad_(True)
+        lengths = [feats_d.size(1)] * feats_d.size(0)
+        enc, *_ = model.encoder(feats_d, lengths)
+        pl, gl, pr, gr = model.decoder(l2r, r2l, enc, lengths)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        ops.join_side_streams()
+        loss_out.copy_(loss.detach())
+        split["feats"], split["dfeats"] = feats, feats_d.grad
+
+    def part_b():
+        split["feats"].backward(split["dfeats"])
+        ops.join_side_streams()
+        split.clear()
+
     def set_coins(i):
         model.decoder.coins_host = patterns[i % len(patterns)]
 
@@ -237,24 +265,40 @@ def main():
     torch.cuda.synchronize()
     log(args, "eager warm-up done")
 
+    use_split = args.workload == "full" and not args.no_graph and (args.split_graph == "on" or (args.split_graph == "auto" and world > 1))
     graph = None
     graphs = []
     if not args.no_graph:
         for i in range(len(patterns)):
             set_coins(i)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap_stream):
-                fwd_bwd()
-            graphs.append(g)
+            if use_split:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=cap_stream):
+                    part_a()
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=cap_stream):      # reads part A's saved activations
+                    part_b()
+                graphs.append((ga, gb))
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap_stream):
+                    fwd_bwd()
+                graphs.append(g)
         graph = graphs[0]
-        log(args, "capture + instantiate done (%d coin patterns)" % len(graphs))
+        log(args, "capture + instantiate done (%d coin patterns%s)" % (len(graphs), ", two graphs per step" if use_split else ""))
         torch.cuda.synchronize()
     step_no = [0]
 
     def step():
         i = step_no[0]
         step_no[0] += 1
-        if graph is not None:
+        if graph is not None and use_split:
+            ga, gb = graphs[i % len(graphs)]
+            ga.replay()
+            exchange.launch("decoder.")      # side stream: runs beside the frontend backward below
+            exchange.launch("encoder.")
+            gb.replay()
+            exchange.finish()                # frontend segment + join
+        elif graph is not None:
             graphs[i % len(graphs)].replay()
             exchange.finish()
         else:
@@ -337,7 +381,7 @@ def main():
             "config": {"workload": ("full SBL 6+6 (Conv3d stem + ResNet-18 + encoder + SBL decoder) fwd+loss+bwd"
                                     if args.workload == "full" else "visual frontend only (Conv3d stem + ResNet-18) fwd+bwd"),
                        "per_gpu_batch": B, "global_batch": B * world, "clip": "29x88x88", "parallelism": "dp%d" % world,
-                       "dropout": not args.no_dropout, "bn": "train", "hipgraph": graph is not None,
+                       "dropout": not args.no_dropout, "bn": "train", "hipgraph": graph is not None, "graphs_per_step": 2 if (graph is not None and use_split) else 1,
                        "decoder_streams": 1 if args.single_stream else 2,
                        "decoder_schedule": "per-step" if args.per_step_decoder else "teacher-forced runs batched",
                        "coin_patterns": len(patterns), "own_argmax_coins": [sum(p_) for p_ in patterns],

@@ -753,6 +753,47 @@ def test_flat_direct_accumulation_and_two_streams_match_plain_autograd(ops, B):
     assert relerr(flat.flat_grad[a:b], 2 * first[a:b]) < 1e-3
 
 
+def test_backward_cut_at_frontend_features_equals_single_backward(ops):
+    """bench.py runs the N>1 step as two hipGraphs: forward + decoder/encoder backward with the tape cut at the frontend
+    features, then the frontend backward from d(loss)/d(features) - so that the decoder / encoder gradient
+    all-reduces overlap the frontend backward.  The two-part backward must produce the single backward's gradients."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    B, T, H, W, ne, nd = 16, 4, 24, 24, 1, 1
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 61)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    grads = []
+    for cut in (False, True):
+        m = build_model(ne, nd).train()
+        flat = dp.FlatModel(m)
+        flat.zero_grad()
+        random.seed(3)
+        if not cut:
+            pl, gl, pr, gr = m(xd, ld, rd)
+            loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+            loss.backward()
+        else:
+            feats = m.visual_frontend(xd.unsqueeze(4).permute(0, 4, 1, 2, 3))
+            feats_d = feats.detach().requires_grad_(True)
+            lengths = [feats_d.size(1)] * B
+            enc, *_ = m.encoder(feats_d, lengths)
+            pl, gl, pr, gr = m.decoder(ld, rd, enc, lengths)
+            loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+            loss.backward()
+            ops.join_side_streams()
+            a, b = flat.ranges["visual_frontend."]
+            assert float(flat.flat_grad[a:b].abs().max()) == 0.0          # nothing reached the frontend yet
+            feats.backward(feats_d.grad)
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        grads.append((flat.flat_grad.clone(), dict(flat.ranges), float(loss.item())))
+    assert abs(grads[0][2] - grads[1][2]) < 1e-6
+    for seg, (a, b) in grads[0][1].items():
+        ref, got = grads[0][0][a:b].double(), grads[1][0][a:b].double()
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel < (3e-2 if seg.startswith("visual") else 1e-4), (seg, rel)      # BN-amplified reorder noise in the frontend
+
+
 def test_device_input_pipeline_bit_exact(ops):
     """uint8 frames -> normalised / cropped / flipped / frame-removed / zero-padded clips, bit-identical to the numpy
     restatement of SBL/data_gen.py + cvtransforms.py (the reference's file needs cv2, absent here)."""
