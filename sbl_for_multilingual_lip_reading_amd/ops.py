@@ -567,10 +567,13 @@ class SDPAFn(torch.autograd.Function):
         ctx.save_for_backward(q, k, v, p, seed)
         ctx.cfg = (H, scale, drop_p, off)
         ctx.mark_non_differentiable(p)
+        ctx.set_materialize_grads(False)      # else autograd zero-fills a gradient for p before every backward
         return o, p
 
     @staticmethod
     def backward(ctx, do, _dp):
+        if do is None:
+            return (None,) * 8
         q, k, v, p, seed = ctx.saved_tensors
         H, scale, drop_p, off = ctx.cfg
         B, Lq, _ = q.shape
@@ -699,10 +702,13 @@ class MHAFn(torch.autograd.Function):
         ctx.gb = (g_qkv, (_gbuf(wfc), _gbuf(bfc)), (_gbuf(gamma), _gbuf(beta)))
         ctx.defer = _collector
         ctx.mark_non_differentiable(p)
+        ctx.set_materialize_grads(False)      # else autograd zero-fills a gradient for p before every backward
         return y, p
 
     @staticmethod
     def backward(ctx, dy, _dp):
+        if dy is None:
+            return (None,) * 19
         x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed = ctx.saved_tensors
         B, segL, Lk, D, H, drop_p, off_a, off_o, self_attn = ctx.cfg
         g_qkv, g_fc, g_ln = ctx.gb
@@ -927,10 +933,13 @@ class SmoothedCEFn(torch.autograd.Function):
         ctx.save_for_backward(pred, gold, out3)
         ctx.cfg = (eps, ignore_id)
         ctx.mark_non_differentiable(out3)
+        ctx.set_materialize_grads(False)
         return out3[0] / out3[1], out3
 
     @staticmethod
     def backward(ctx, gloss, _g3):
+        if gloss is None:
+            return None, None, None, None
         pred, gold, out3 = ctx.saved_tensors
         eps, ignore_id = ctx.cfg
         R, C = pred.shape

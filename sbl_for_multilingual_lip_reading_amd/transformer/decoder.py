@@ -198,8 +198,10 @@ class Decoder(nn.Module):
             for d in (0, 1):
                 last = ops.GatherLastFn.apply(x[d], N, segL)           # (nseg*N, 512): position -1 of every prefix
                 pred = ops.linear(last, heads[d])                      # (nseg*N, 58)
-                for s, step in enumerate(range(i0, i1 + 1)):
-                    outs[d][step] = pred[s * N:(s + 1) * N]
+                # unbind (one stack in backward) instead of row slices (a zero-filled (nseg*N, 58) buffer, a copy and
+                # an add per step in backward)
+                for step, pr in zip(range(i0, i1 + 1), pred.view(len(segL), N, -1).unbind(0)):
+                    outs[d][step] = pr
             # token fed to the next stage
             if coins is None:
                 for d in (0, 1):

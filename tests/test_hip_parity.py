@@ -787,7 +787,7 @@ def test_backward_cut_at_frontend_features_equals_single_backward(ops):
         ops.join_side_streams()
         torch.cuda.synchronize()
         grads.append((flat.flat_grad.clone(), dict(flat.ranges), float(loss.item())))
-    assert abs(grads[0][2] - grads[1][2]) < 1e-6
+    assert abs(grads[0][2] - grads[1][2]) < 2e-5      # two fresh forward passes: BN statistics are summed with atomics
     for seg, (a, b) in grads[0][1].items():
         ref, got = grads[0][0][a:b].double(), grads[1][0][a:b].double()
         rel = float((got - ref).norm() / ref.norm())
