@@ -118,10 +118,11 @@ int sbl_bn_apply_fwd(const float* x, const float* res, const float* mean, const 
  * then fp32 scratch): block partials + a last-arriver reduction replace 2C contended double atomics per block. */
 int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                       double* sums, long rows, int C, int relu, void* ws, long ws_bytes, sbl_stream_t stream);
-/* dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (if non-null); dgamma, dbeta from sums */
+/* dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (if non-null); dgamma, dbeta from sums
+ * (accumulate != 0: += into the persistent gradient buffers) */
 int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const double* sums, float* dx, float* dres, float* dgamma, float* dbeta,
-                     long rows, int C, int relu, sbl_stream_t stream);
+                     long rows, int C, int relu, int accumulate, sbl_stream_t stream);
 
 /* ---------------------------------------------------------------- ResNet-18 trunk convolutions
  * conv3x3 / 1x1-stride-2, bias-free, NHWC implicit GEMM: SBL/transformer/video_frontend.py:10-12,69-70.

@@ -23,7 +23,7 @@ SIGNATURES = {
     "sbl_bn_eval_stats": [P, P, F, P, P, I, P],
     "sbl_bn_apply_fwd": [P, P, P, P, P, P, P, L, I, I, P],
     "sbl_bn_bwd_reduce": [P, P, P, P, P, P, L, I, I, P, L, P],
-    "sbl_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, P],
+    "sbl_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "sbl_conv_weight_pack": [P, P, P, I, I, I, I, P],
     "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, I, P],
     "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],

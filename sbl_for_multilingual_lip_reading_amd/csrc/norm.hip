@@ -168,13 +168,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, float* __restrict__ dx,
                                                            float* __restrict__ dres, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, long n4, long rows, int C, int relu) {
+                                                           float* __restrict__ dbeta, long n4, long rows, int C, int relu,
+                                                           int accumulate) {
     const int C4 = C / 4;
     const double inv = 1.0 / (double)rows;
     if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += 256) {
-            dbeta[c] = (float)sums[c];
-            dgamma[c] = (float)sums[C + c];
+        for (int c = threadIdx.x; c < C; c += 256) {      // one writer: += is safe
+            dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
+            dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
         }
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
@@ -253,12 +254,12 @@ extern "C" int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x
 
 extern "C" int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                                 const float* gamma, const double* sums, float* dx, float* dres, float* dgamma,
-                                float* dbeta, long rows, int C, int relu, sbl_stream_t stream) {
+                                float* dbeta, long rows, int C, int relu, int accumulate, sbl_stream_t stream) {
     SBL_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && dgamma && dbeta && rows > 0 && C >= 4 && C % 4 == 0 && (!relu || y),
                 "sbl_bn_bwd_apply: bad args");
     const long n4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, invstd,
-                       gamma, sums, dx, dres, dgamma, dbeta, n4, rows, C, relu);
+                       gamma, sums, dx, dres, dgamma, dbeta, n4, rows, C, relu, accumulate);
     SBL_LAUNCH_CHECK("sbl_bn_bwd_apply");
     return 0;
 }

@@ -1035,6 +1035,7 @@ class ConvBNFn(torch.autograd.Function):
              int(relu), _s())
         ctx.save_for_backward(x, w, conv, y if relu else None, mean, invstd, gamma, w_dg)
         ctx.cfg = (relu, stride, pad, training, res is not None)
+        ctx.gb_bn = (_gbuf(gamma), _gbuf(beta))
         return y
 
     @staticmethod
@@ -1053,10 +1054,15 @@ class ConvBNFn(torch.autograd.Function):
              _workspace().data_ptr(), WS_BYTES, _s())
         dconv = torch.empty_like(conv)
         dres = torch.empty_like(conv) if has_res else None
-        dgamma = torch.empty(Cout, device=dev, dtype=torch.float32)
-        dbeta = torch.empty(Cout, device=dev, dtype=torch.float32)
-        call("sbl_bn_bwd_apply", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dconv), _p(dres),
-             _p(dgamma), _p(dbeta), rows, Cout, int(relu), _s())
+        if ctx.gb_bn[0] is not None and ctx.gb_bn[1] is not None:      # persistent gradient buffers: += in the kernel
+            call("sbl_bn_bwd_apply", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dconv), _p(dres),
+                 _p(ctx.gb_bn[0]), _p(ctx.gb_bn[1]), rows, Cout, int(relu), 1, _s())
+            dgamma = dbeta = None
+        else:
+            dgamma = torch.empty(Cout, device=dev, dtype=torch.float32)
+            dbeta = torch.empty(Cout, device=dev, dtype=torch.float32)
+            call("sbl_bn_bwd_apply", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dconv), _p(dres),
+                 _p(dgamma), _p(dbeta), rows, Cout, int(relu), 0, _s())
         dx = None
         if ctx.needs_input_grad[0]:
             if w_dg is None:
