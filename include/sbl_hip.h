@@ -133,11 +133,13 @@ int sbl_conv_weight_pack(const float* w_oihw, float* w_ohwi, float* w_dgrad /*[C
 /* accumulate != 0: dw_oihw += (the persistent flat gradient buffer of a data-parallel replica) */
 int sbl_conv_wgrad_unpack(const float* dw_ohwi, float* dw_oihw, int Cout, int Cin, int KH, int KW, int accumulate,
                           sbl_stream_t stream);
-/* stats: NULL or double[2*Cout] (sum, sumsq of y) accumulated by the epilogue; zeroed by the call */
+/* stats: NULL or double[2*Cout] (sum, sumsq of y) accumulated by the epilogue; zeroed by the call.
+ * ws / ws_bytes (may be NULL/0): the calling stream's sbl_gemm_f32 workspace.  With it, a launch whose tile count
+ * is not a multiple of the 256 CUs runs its last partial round of tiles split along K (in-launch slab reduction). */
 int sbl_conv2d_fwd(const float* x, const float* w_ohwi, float* y, double* stats, int NIMG, int H, int W, int Cin,
-                   int Cout, int KH, int KW, int stride, int pad, sbl_stream_t stream);
+                   int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream);
 int sbl_conv2d_dgrad(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
-                     int KH, int KW, int stride, int pad, sbl_stream_t stream);
+                     int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream);
 /* dw_ohwi zeroed by the call, then split-K float atomics */
 int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, int NIMG, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad, sbl_stream_t stream);

@@ -26,8 +26,8 @@ SIGNATURES = {
     "sbl_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "sbl_conv_weight_pack": [P, P, P, I, I, I, I, P],
     "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, I, P],
-    "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "sbl_avgpool_fwd": [P, P, I, I, I, P],
     "sbl_avgpool_bwd": [P, P, I, I, I, P],

@@ -15,8 +15,11 @@ static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout
 }
 static inline int out_dim(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
 
+#define SBL_CONV_WS_COUNTERS 4096      // same workspace convention as sbl_gemm_f32: int counters, then fp32 slabs
+static const int g_tailsplit = getenv("SBL_CONV_TAILSPLIT") ? atoi(getenv("SBL_CONV_TAILSPLIT")) : 1;   // A/B knob
+
 extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* stats, int NIMG, int H, int W, int Cin,
-                              int Cout, int KH, int KW, int stride, int pad, sbl_stream_t stream) {
+                              int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_conv("sbl_conv2d_fwd", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(x && w && y && sbl_aligned16(x) && sbl_aligned16(w), "sbl_conv2d_fwd: null/unaligned pointer");
@@ -25,17 +28,23 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
-    SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};
+    SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_fwd: workspace unaligned or < 16 KiB");
 #define SBL_CONV_FWD(BM, BN, WN)                                                                               \
     do {                                                                                                       \
         ConvGatherKC<BM, false> al{x, g, M};                                                                   \
         DenseKC<BN, true> bl{w, (long)K, N};                                                                   \
         if (stats) {                                                                                           \
             EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0};                                    \
-            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_FWD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};                 \
+                sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            }                                                                                                  \
         } else {                                                                                               \
             EpiStore<0, false> e{y, (long)N, nullptr, 0, nullptr, nullptr, 0};                                 \
-            sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_FWD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};                 \
+                sbl_launch_gemm<ConvGatherKC<BM, false>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            }                                                                                                  \
         }                                                                                                      \
     } while (0)
     // all tiles are co-resident (<= 4 workgroups per CU), so the launch lasts as long as the fullest CU: pick the
@@ -53,7 +62,7 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
 }
 
 extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
-                                int KH, int KW, int stride, int pad, sbl_stream_t stream) {
+                                int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_conv("sbl_conv2d_dgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(dy && wt && dx && sbl_aligned16(dy) && sbl_aligned16(wt), "sbl_conv2d_dgrad: null/unaligned pointer");
@@ -97,13 +106,16 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
     const int M = NIMG * H * W, N = Cin, K = KH * KW * Cout;
     ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
-    SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
+    SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_dgrad: workspace unaligned or < 16 KiB");
 #define SBL_CONV_DG(BM, BN, WN)                                                                               \
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
         DenseKC<BN, true> bl{wt, (long)K, N};                                                                 \
         EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
-        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+        if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+            SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                  \
+            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+        }                                                                                                     \
     } while (0)
     static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
     const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;

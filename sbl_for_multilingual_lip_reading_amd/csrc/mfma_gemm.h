@@ -653,10 +653,11 @@ __device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const 
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2>
 __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
-                                                            int kchunk) {
+                                                            int kchunk, int x_off) {
     const int kbeg = blockIdx.z * kchunk;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, blockIdx.x * BM, blockIdx.y * BN, kbeg, min(K, kbeg + kchunk),
-                                               blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, gridDim.z, blockIdx.y == 0);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, (blockIdx.x + x_off) * BM, blockIdx.y * BN, kbeg,
+                                               min(K, kbeg + kchunk), blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, gridDim.z,
+                                               blockIdx.y == 0);
 }
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>
@@ -666,5 +667,35 @@ static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, i
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk);
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk, 0);
+}
+
+// Tail splitting.  Every tile of these launches is resident at once, so a launch lasts as long as its fullest CU:
+// T tiles on 256 CUs run at ceil(T/256) tiles per CU.  Here the first floor(T/256)*256 tiles (whole M-tile columns of
+// them) run unsplit and the remaining M-tile columns run as a second launch with K split `sp` ways - about one
+// short workgroup per CU - reduced in-launch through the slab workspace (last arriver runs the full epilogue, so BN
+// statistics / bias / ReLU work unchanged).  Returns false (nothing launched) when it does not apply.
+template <class AL, class BL, class EPI, int BM, int BN, int KU = 1>
+static inline bool sbl_launch_gemm_tailsplit(const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, hipStream_t s,
+                                             int stamp_kid, void* ws, long ws_bytes, int ws_counters) {
+    constexpr int MK = KU * SBL_BK;
+    const int X = sbl_cdiv(M, BM), Y = sbl_cdiv(N, BN);
+    const long T = (long)X * Y;
+    if (!ws || T <= 256 || T > 2048) return false;
+    const int XA = (int)((T / 256) * 256 / Y);                 // whole columns of M tiles in the unsplit part
+    const long rem = T - (long)XA * Y;
+    if (XA <= 0 || rem <= 0 || rem > 176) return false;       // a nearly full last round gains nothing
+    int sp = (int)(256 / rem);
+    if (sp > K / (4 * MK)) sp = K / (4 * MK);                  // chunks of at least 4 macro steps
+    if (sp > 8) sp = 8;
+    if (sp < 2 || rem > ws_counters) return false;
+    const long need = (long)sizeof(int) * ws_counters + rem * sp * (long)(BM * BN * sizeof(float));
+    if (need > ws_bytes) return false;
+    SplitCtl sa{nullptr, nullptr, nullptr, sbl_next_stamp_slot(stamp_kid)};
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(XA, Y, 1), dim3(256), 0, s, al, bl, epi, sa, M, N, K, K, 0);
+    SplitCtl sb{(float*)((char*)ws + sizeof(int) * ws_counters), (int*)ws, nullptr, sbl_next_stamp_slot(stamp_kid)};
+    const int kchunk = sbl_cdiv(sbl_cdiv(K, sp), MK) * MK;
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(X - XA, Y, sbl_cdiv(K, kchunk)), dim3(256), 0, s, al, bl,
+                       epi, sb, M, N, K, kchunk, XA);
+    return true;
 }

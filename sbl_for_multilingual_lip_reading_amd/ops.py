@@ -1023,11 +1023,13 @@ class ConvBNFn(torch.autograd.Function):
         invstd = torch.empty(Cout, device=dev, dtype=torch.float32)
         if training:
             stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), _p(stats), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), _p(stats), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                 _workspace().data_ptr(), WS_BYTES, _s())
             call("sbl_bn_finalize", _p(stats), NIMG * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps, _p(mean),
                  _p(invstd), Cout, _s())
         else:
-            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), None, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), None, NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                 _workspace().data_ptr(), WS_BYTES, _s())
             call("sbl_bn_eval_stats", _p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), Cout, _s())
         y = torch.empty_like(conv)
         r = None if res is None else res.contiguous()
@@ -1070,7 +1072,8 @@ class ConvBNFn(torch.autograd.Function):
                 w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
                 call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
             dx = torch.empty_like(x)
-            call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+            call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                 _workspace().data_ptr(), WS_BYTES, _s())
         gw = _gbuf(w)
         _side_join["n"] = _side_join.get("n", 0) + 1
         if gw is not None and CONV_WGRAD_SIDE and (CONV_WGRAD_SIDE_EVERY <= 1 or _side_join["n"] % CONV_WGRAD_SIDE_EVERY == 0):
