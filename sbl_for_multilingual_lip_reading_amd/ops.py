@@ -120,11 +120,16 @@ CONV_WGRAD_SIDE = os.environ.get("SBL_CONV_WGRAD_SIDE", "1") != "0"
 # the second stream also carries the merged decoder weight-gradient GEMMs during the frontend backward; only every
 # k-th trunk dW goes there so that neither stream becomes the longer one
 CONV_WGRAD_SIDE_EVERY = int(os.environ.get("SBL_CONV_WGRAD_SIDE_EVERY", "1"))
-_side_join = {"armed": False}
+_side_join_state = {}      # per device: nn.DataParallel drives one replica per device from its own thread
+
+
+def _side_join_for_current_device():
+    return _side_join_state.setdefault(torch.cuda.current_device(), {"armed": False, "n": 0})
 
 
 def _arm_side_join():
     """Once per backward: make the stream that finishes backward wait for the side stream."""
+    _side_join = _side_join_for_current_device()
     if not _side_join["armed"]:
         _side_join["armed"] = True
 
@@ -187,7 +192,8 @@ class WgradCollector:
         e["rows"].append(rows)
         if not self.armed:
             self.armed = True
-            _armed.append(self)
+            self.device_index = torch.cuda.current_device()
+            _armed.setdefault(self.device_index, []).append(self)
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
 
     def flush(self):
@@ -252,37 +258,38 @@ class WgradCollector:
         if side is not None and cur != side:
             cur.wait_stream(side)
         self.armed = False
-        if self in _armed:
-            _armed.remove(self)
+        lst = _armed.get(getattr(self, "device_index", -1), [])
+        if self in lst:
+            lst.remove(self)
 
 
 FLUSH_ON_SIDE = os.environ.get("SBL_FLUSH_ON_SIDE", "1") != "0"
 GROUP_WGRAD = os.environ.get("SBL_GROUP_WGRAD", "1") != "0"
 FLUSH_AT_DECODER_END = os.environ.get("SBL_FLUSH_AT_DECODER_END", "1") == "1"
 _group_tables = {}
-_armed = []
+_armed = {}       # device index -> collectors with pending entries
 
 
 def flush_deferred():
     """Issue every deferred weight-gradient GEMM collected so far (idempotent).  dp.GradientExchange calls this
     before it all-reduces the decoder segment; the decoder calls it from its encoder_outputs gradient hook."""
-    for c in list(_armed):
+    for c in list(_armed.get(torch.cuda.current_device(), [])):
         c.flush()
 
 
 DEFER_WGRAD = os.environ.get("SBL_DEFER_WGRAD", "1") != "0"
-_collector = None
+import threading as _threading
+
+_tls = _threading.local()      # the collector of the forward pass running on THIS thread (nn.DataParallel: one per replica)
 
 
 def begin_defer():
     """Decoder forward: tape nodes created from here on defer their weight gradients (if enabled)."""
-    global _collector
-    _collector = WgradCollector() if DEFER_WGRAD else None
+    _tls.collector = WgradCollector() if DEFER_WGRAD else None
 
 
 def end_defer():
-    global _collector
-    _collector = None
+    _tls.collector = None
 
 
 def wgrad_gemm(M, N, K, A, lda, B, ldb, C, ldc, acc, colsum, defer=None):
@@ -700,7 +707,7 @@ class MHAFn(torch.autograd.Function):
         ctx.save_for_backward(x2, kv, qkv, att, p, o, mean, rstd, wq, wk, wv, wfc, gamma, seed)
         ctx.cfg = (B, tuple(segL), Lk, D, H, drop_p, off_a, off_o, self_attn)
         ctx.gb = (g_qkv, (_gbuf(wfc), _gbuf(bfc)), (_gbuf(gamma), _gbuf(beta)))
-        ctx.defer = _collector
+        ctx.defer = getattr(_tls, "collector", None)
         ctx.mark_non_differentiable(p)
         ctx.set_materialize_grads(False)      # else autograd zero-fills a gradient for p before every backward
         return y, p
@@ -791,7 +798,7 @@ class FFNFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h, o, mean, rstd, w1, w2, gamma, seed)
         ctx.cfg = (shp, drop_p, off)
         ctx.gb = ((_gbuf(w1), _gbuf(b1)), (_gbuf(w2), _gbuf(b2)), (_gbuf(gamma), _gbuf(beta)))
-        ctx.defer = _collector
+        ctx.defer = getattr(_tls, "collector", None)
         return y.view(shp)
 
     @staticmethod
@@ -1075,7 +1082,8 @@ class ConvBNFn(torch.autograd.Function):
             call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                  _workspace().data_ptr(), WS_BYTES, _s())
         gw = _gbuf(w)
-        _side_join["n"] = _side_join.get("n", 0) + 1
+        _side_join = _side_join_for_current_device()
+        _side_join["n"] += 1
         if gw is not None and CONV_WGRAD_SIDE and (CONV_WGRAD_SIDE_EVERY <= 1 or _side_join["n"] % CONV_WGRAD_SIDE_EVERY == 0):
             # the weight gradient is off backward's dependency chain: with a persistent gradient buffer it is issued
             # on the second stream, where its workgroups fill the CUs that the chain's kernels (tile-count
