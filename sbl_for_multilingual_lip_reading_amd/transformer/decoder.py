@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from ._env import config, ops
+from . import decoder_stages
 from .attention import MultiHeadAttention
 from .module import PositionalEncoding, PositionwiseFeedForward
 from .utils import get_attn_key_pad_mask, get_attn_pad_mask, get_non_pad_mask, get_subsequent_mask, pad_list
@@ -74,6 +75,7 @@ class Decoder(nn.Module):
         self.tgt_word_prj_l2r = nn.Linear(512, 58, bias=False)
         self.tgt_word_prj_r2l = nn.Linear(512, 58, bias=False)
 
+        self.batched_backward = True     # one stage-batched backward over all 16 steps (decoder_stages.py) when possible
         self.two_streams = True          # run the two directions' layers on two HIP streams (joined before each fusion)
         self.batch_teacher_runs = True   # batch the steps of a teacher-forced run (see class docstring)
         self.coins_dev = None            # optional device int32[16]: 1 = feed own argmax (graph replay, per-step schedule)
@@ -226,6 +228,16 @@ class Decoder(nn.Module):
         dev = encoder_outputs.device
         ys_in_pad_l2r, ys_out_pad_l2r = self.preprocess(padded_input_l2r.to(dev))
         ys_in_pad_r2l, ys_out_pad_r2l = self.preprocess(padded_input_r2l.to(dev))
+        if decoder_stages.supported(self, encoder_outputs):
+            # same coins, same order as _run / decoder.py:176
+            if self.coins_host is not None:
+                coins = [bool(c) for c in self.coins_host]
+            else:
+                coins = [random.random() > config.TEACHER_COIN_THRESHOLD for _ in range(config.MAX_DECODE_LEN)]
+            self.last_coins = coins
+            pl, pr = decoder_stages.DecoderStagesFn.apply(encoder_outputs, self.tgt_word_emb.weight, self, ys_out_pad_l2r,
+                                                          ys_out_pad_r2l, coins)
+            return pl, ys_out_pad_l2r, pr, ys_out_pad_r2l
         outs, _ = self._run(encoder_outputs, ys_out_pad_l2r, ys_out_pad_r2l, teacher_mode=True)
         return torch.stack(outs[0], 1), ys_out_pad_l2r, torch.stack(outs[1], 1), ys_out_pad_r2l
 

@@ -1,0 +1,381 @@
+"""The SBL decoder's 16 steps as ONE autograd node with a stage-batched backward.
+
+Forward has to run stage by stage: a stage (a maximal run of teacher-forced steps, see Decoder._run) needs the
+previous stage's argmax token (decoder.py:173-186).  Backward has no such dependency - tokens are not differentiable -
+so the backward of ALL 16 steps is one ragged batch: per layer and direction one LayerNorm / attention / GEMM launch
+over the N*136 rows of every step, instead of one per stage.  The dependent chain shrinks from
+11 kernels x 6 layers x (1 + #own-argmax coins) to 11 x 6, and its GEMMs are 4352-row products instead of 100-1500.
+
+To make that possible every stage's forward writes its activations into row ranges of per-layer buffers laid out
+as the 16-segment ragged batch (segment t = the step with prefix length t+1, rows N*t*(t+1)/2 ...), with the raw
+C-ABI kernels (no per-op tape).  Dropout masks are functions of (seed, stream offset, element index); a stage passes
+an offset that folds its row base in (the generator is affine in both, see _fold), so the batched backward
+regenerates exactly the masks of the forward with plain whole-buffer indices.
+
+Used by Decoder.forward when gradients accumulate into persistent buffers (dp.FlatModel) and the coins are known on
+the host; every other case keeps the per-stage tape (Decoder._run).  Same numbers as that path (tests compare them).
+"""
+import torch
+
+from ._env import config, ops
+
+_C1 = 0x9E3779B97F4A7C15
+_C2 = 0xD1B54A32D192ED03
+_K = (_C2 * pow(_C1, -1, 1 << 64)) % (1 << 64)
+_MASK = (1 << 64) - 1
+
+
+def _fold(offset, base):
+    """Stream offset that makes element i of a sub-tensor draw what element base+i of the whole tensor draws:
+    sbl_rand_u32 hashes seed + C1*(offset+1) + C2*idx in wrap-around 64-bit arithmetic and C1 is odd."""
+    return ((offset + 1 + base * _K) & _MASK) - 1 & _MASK
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def supported(dec, encoder_outputs):
+    """The fast path needs persistent gradient buffers for every decoder parameter (kernels accumulate there), host
+    coins, CUDA, and the 6-layer / 512-wide geometry the buffers are laid out for."""
+    if not (dec.batched_backward and encoder_outputs.is_cuda and torch.is_grad_enabled() and dec.coins_dev is None):
+        return False
+    if dec.d_model != 512 or not dec.batch_teacher_runs:
+        return False
+    return all(ops._gbuf(p) is not None for p in dec.parameters())
+
+
+class _Layer:
+    """Parameter handles of one DecoderLayer (fused QKV weights of the self-attention are adjacent rows)."""
+
+    def __init__(self, lay):
+        lay.slf_attn._fuse()
+        lay.enc_attn._fuse()
+        sa, ea, ff = lay.slf_attn, lay.enc_attn, lay.pos_ffn
+        self.wqkv, self.bqkv = sa.w_qs.weight, sa.w_qs.bias                  # first of three adjacent blocks
+        assert ops._adjacent(sa.w_qs.weight, sa.w_ks.weight, sa.w_vs.weight) and ops._adjacent(sa.w_qs.bias, sa.w_ks.bias, sa.w_vs.bias)
+        gw = [ops._gbuf(t) for t in (sa.w_qs.weight, sa.w_ks.weight, sa.w_vs.weight)]
+        gb = [ops._gbuf(t) for t in (sa.w_qs.bias, sa.w_ks.bias, sa.w_vs.bias)]
+        assert ops._adjacent(*gw) and ops._adjacent(*gb)
+        self.g_wqkv, self.g_bqkv = gw[0], gb[0]
+        self.wfc_s, self.bfc_s, self.g_wfc_s, self.g_bfc_s = sa.fc.weight, sa.fc.bias, ops._gbuf(sa.fc.weight), ops._gbuf(sa.fc.bias)
+        self.ln_s = (sa.layer_norm.weight, sa.layer_norm.bias, ops._gbuf(sa.layer_norm.weight), ops._gbuf(sa.layer_norm.bias), sa.layer_norm.eps)
+        self.wq, self.bq, self.g_wq, self.g_bq = ea.w_qs.weight, ea.w_qs.bias, ops._gbuf(ea.w_qs.weight), ops._gbuf(ea.w_qs.bias)
+        assert ops._adjacent(ea.w_ks.weight, ea.w_vs.weight) and ops._adjacent(ea.w_ks.bias, ea.w_vs.bias)
+        self.wkv, self.bkv = ea.w_ks.weight, ea.w_ks.bias
+        gkw, gkb = [ops._gbuf(t) for t in (ea.w_ks.weight, ea.w_vs.weight)], [ops._gbuf(t) for t in (ea.w_ks.bias, ea.w_vs.bias)]
+        assert ops._adjacent(*gkw) and ops._adjacent(*gkb)
+        self.g_wkv, self.g_bkv = gkw[0], gkb[0]
+        self.wfc_e, self.bfc_e, self.g_wfc_e, self.g_bfc_e = ea.fc.weight, ea.fc.bias, ops._gbuf(ea.fc.weight), ops._gbuf(ea.fc.bias)
+        self.ln_e = (ea.layer_norm.weight, ea.layer_norm.bias, ops._gbuf(ea.layer_norm.weight), ops._gbuf(ea.layer_norm.bias), ea.layer_norm.eps)
+        self.w1, self.b1, self.g_w1, self.g_b1 = ff.w_1.weight, ff.w_1.bias, ops._gbuf(ff.w_1.weight), ops._gbuf(ff.w_1.bias)
+        self.w2, self.b2, self.g_w2, self.g_b2 = ff.w_2.weight, ff.w_2.bias, ops._gbuf(ff.w_2.weight), ops._gbuf(ff.w_2.bias)
+        self.ln_f = (ff.layer_norm.weight, ff.layer_norm.bias, ops._gbuf(ff.layer_norm.weight), ops._gbuf(ff.layer_norm.bias), ff.layer_norm.eps)
+        self.drop_s = sa.dropout.p if sa.training else 0.0
+        self.drop_e = ea.dropout.p if ea.training else 0.0
+        self.drop_f = ff.dropout.p if ff.training else 0.0
+
+
+class DecoderStagesFn(torch.autograd.Function):
+    """(encoder_outputs, anchor parameter) -> (pred_l2r, pred_r2l), each (N, 16, 58).  `anchor` is any decoder
+    parameter: it only makes the outputs require grad when the encoder is frozen."""
+
+    @staticmethod
+    def forward(ctx, enc_out, anchor, dec, gold_l2r, gold_r2l, coins):
+        call, gemm, segs = ops.call, ops.gemm, ops._segs
+        dev = enc_out.device
+        N, T, D = enc_out.shape
+        H, HD, F_, V = 8, 512, dec.layer_first_l2r.pos_ffn.w_1.weight.size(0), dec.tgt_word_emb.weight.size(0)
+        ML = config.MAX_DECODE_LEN
+        nl = dec.n_layers
+        R = N * ML * (ML + 1) // 2
+        rowoff = [N * t * (t + 1) // 2 for t in range(ML + 1)]                        # segment t = prefix length t+1
+        ps_off = [H * N * sum((u + 1) ** 2 for u in range(t)) for t in range(ML + 1)]  # self-attention probabilities
+        pe_off = [H * N * T * sum(u + 1 for u in range(t)) for t in range(ML + 1)]     # cross-attention probabilities
+        layers = [[_Layer(l) for l in dec._layers(d)] for d in (0, 1)]
+        enc2 = enc_out.contiguous().view(N * T, D)
+        main = torch.cuda.current_stream(dev)
+        side = ops.side_stream(dev) if dec.two_streams else None
+        ops.set_main_stream(main)
+        streams = (main, side if side is not None else main)
+        st = ops.dropout_state(dev)
+        training = dec.training
+        p_emb = dec.dropout.p if training else 0.0
+
+        def E(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+        # ---- all-stage buffers
+        B_ = [[None] * nl for _ in (0, 1)]
+        for d in (0, 1):
+            for n in range(nl):
+                B_[d][n] = dict(x=E(R, D), qkv=E(R, 3 * HD), att=E(R, HD), ps=E(ps_off[ML]), o_s=E(R, D), mu_s=E(R), rs_s=E(R), y_s=E(R, D),
+                                q=E(R, HD), att2=E(R, HD), pe=E(pe_off[ML]), o_e=E(R, D), mu_e=E(R), rs_e=E(R), y_e=E(R, D),
+                                h=E(R, F_), o_f=E(R, D), mu_f=E(R), rs_f=E(R), y_f=E(R, D), kv=E(N * T, 2 * HD),
+                                off=[st.next_offset() for _ in range(5)] if training else [0] * 5)
+        xout = [E(R, D), E(R, D)]
+        x0 = [E(R, D) if p_emb > 0 else None for _ in (0, 1)]        # pre-dropout embeddings are not needed afterwards
+        off_emb = [st.next_offset() if p_emb > 0 else 0 for _ in (0, 1)]
+        last = [E(ML * N, D), E(ML * N, D)]
+        pred = [E(ML * N, V), E(ML * N, V)]
+        heads = (dec.tgt_word_prj_l2r.weight, dec.tgt_word_prj_r2l.weight)
+        emb, pe_tab = dec.tgt_word_emb.weight, dec.positional_encoding.pe[0]
+        golds = (gold_l2r, gold_r2l)
+        ys = [torch.full((N, ML + 1), dec.eos_id, dtype=torch.long, device=dev) for _ in (0, 1)]
+        for y in ys:
+            y[:, 0] = dec.sos_id
+        seed = st.seed
+
+        # ---- hoisted cross-attention K/V, one GEMM per layer and direction (r2l on the side stream)
+        if side is not None:
+            side.wait_stream(main)
+        for d in (0, 1):
+            with torch.cuda.stream(streams[d]):
+                for n in range(nl):
+                    L = layers[d][n]
+                    gemm(0, 1, N * T, 2 * HD, D, enc2, D, L.wkv, D, B_[d][n]["kv"], 2 * HD, bias=L.bkv)
+
+        # ---- stages (same rule as Decoder._run)
+        stages, i = [], 0
+        while i < ML:
+            j = i
+            while j < ML - 1 and not coins[j]:
+                j += 1
+            stages.append((i, j))
+            i = j + 1
+        for k in range(ML):
+            if not coins[k]:
+                for d in (0, 1):
+                    ops.argmax_select(None, golds[d], ys[d], k, 0)
+
+        def layer_fwd(d, n, r0, r1, i0, segL):
+            L, b = layers[d][n], B_[d][n]
+            M = r1 - r0
+            seg_arr, nseg = segs(segL)
+            x = b["x"][r0:r1]
+            # self-attention sub-layer
+            qkv = b["qkv"][r0:r1]
+            gemm(0, 1, M, 3 * HD, D, x, D, L.wqkv, D, qkv, 3 * HD, bias=L.bqkv)
+            call("sbl_attention_seg_fwd", _p(qkv), 3 * HD, _p(qkv[:, HD:]), 3 * HD, _p(qkv[:, 2 * HD:]), 3 * HD, _p(b["att"][r0:r1]), HD,
+                 b["ps"].data_ptr() + 4 * ps_off[i0], 1 if n == 0 else 0, None, N, H, seg_arr, nseg, 0, 0.125, L.drop_s,
+                 _p(seed) if L.drop_s > 0 else None, _fold(b["off"][0], ps_off[i0]), ops._s())
+            gemm(0, 1, M, D, HD, b["att"][r0:r1], HD, L.wfc_s, HD, b["o_s"][r0:r1], D, bias=L.bfc_s)
+            g, be, _, _, eps = L.ln_s
+            call("sbl_add_layernorm_fwd", _p(b["o_s"][r0:r1]), _p(x), _p(g), _p(be), _p(b["y_s"][r0:r1]), _p(b["mu_s"][r0:r1]),
+                 _p(b["rs_s"][r0:r1]), M, D, eps, L.drop_s, _p(seed) if L.drop_s > 0 else None, _fold(b["off"][1], r0 * D), ops._s())
+            # cross-attention sub-layer
+            y_s, q = b["y_s"][r0:r1], b["q"][r0:r1]
+            gemm(0, 1, M, HD, D, y_s, D, L.wq, D, q, HD, bias=L.bq)
+            kv = b["kv"]
+            call("sbl_attention_seg_fwd", _p(q), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(b["att2"][r0:r1]), HD,
+                 b["pe"].data_ptr() + 4 * pe_off[i0], 0, None, N, H, seg_arr, nseg, T, 0.125, L.drop_e,
+                 _p(seed) if L.drop_e > 0 else None, _fold(b["off"][2], pe_off[i0]), ops._s())
+            gemm(0, 1, M, D, HD, b["att2"][r0:r1], HD, L.wfc_e, HD, b["o_e"][r0:r1], D, bias=L.bfc_e)
+            g, be, _, _, eps = L.ln_e
+            call("sbl_add_layernorm_fwd", _p(b["o_e"][r0:r1]), _p(y_s), _p(g), _p(be), _p(b["y_e"][r0:r1]), _p(b["mu_e"][r0:r1]),
+                 _p(b["rs_e"][r0:r1]), M, D, eps, L.drop_e, _p(seed) if L.drop_e > 0 else None, _fold(b["off"][3], r0 * D), ops._s())
+            # position-wise feed-forward sub-layer
+            y_e, h = b["y_e"][r0:r1], b["h"][r0:r1]
+            gemm(0, 1, M, F_, D, y_e, D, L.w1, D, h, F_, bias=L.b1, relu=1)
+            gemm(0, 1, M, D, F_, h, F_, L.w2, F_, b["o_f"][r0:r1], D, bias=L.b2)
+            g, be, _, _, eps = L.ln_f
+            call("sbl_add_layernorm_fwd", _p(b["o_f"][r0:r1]), _p(y_e), _p(g), _p(be), _p(b["y_f"][r0:r1]), _p(b["mu_f"][r0:r1]),
+                 _p(b["rs_f"][r0:r1]), M, D, eps, L.drop_f, _p(seed) if L.drop_f > 0 else None, _fold(b["off"][4], r0 * D), ops._s())
+
+        for (i0, i1) in stages:
+            segL = tuple(range(i0 + 1, i1 + 2))
+            seg_arr, nseg = segs(segL)
+            r0, r1 = rowoff[i0], rowoff[i1 + 1]
+            M = r1 - r0
+            for d in (0, 1):
+                dst = x0[d][r0:r1] if p_emb > 0 else B_[d][0]["x"][r0:r1]
+                call("sbl_embed_pe_seg_fwd", _p(ys[d]), ys[d].stride(0), _p(emb), _p(pe_tab), _p(dst), N, seg_arr, nseg, D, V, ops._s())
+                if p_emb > 0:
+                    call("sbl_dropout", _p(dst), _p(B_[d][0]["x"][r0:r1]), M * D, p_emb, _p(seed), _fold(off_emb[d], r0 * D), ops._s())
+            for n in range(nl):
+                if side is not None:
+                    side.wait_stream(main)
+                for d in (0, 1):
+                    with torch.cuda.stream(streams[d]):
+                        layer_fwd(d, n, r0, r1, i0, segL)
+                if side is not None:
+                    main.wait_stream(side)
+                nxt = [B_[d][n + 1]["x"][r0:r1] if n + 1 < nl else xout[d][r0:r1] for d in (0, 1)]
+                call("sbl_fusion_seg_fwd", _p(B_[0][n]["y_f"][r0:r1]), _p(B_[1][n]["y_f"][r0:r1]), _p(nxt[0]), _p(nxt[1]), N, seg_arr, nseg,
+                     D, ops._s())
+            for d in (0, 1):
+                lrows = slice(i0 * N, (i1 + 1) * N)
+                call("sbl_gather_last_fwd", _p(xout[d][r0:r1]), _p(last[d][lrows]), N, seg_arr, nseg, D, ops._s())
+                gemm(0, 1, nseg * N, V, D, last[d][lrows], D, heads[d], D, pred[d][lrows], V)
+            if coins[i1]:
+                for d in (0, 1):
+                    ops.argmax_select(pred[d][i1 * N:(i1 + 1) * N], golds[d], ys[d], i1, 1)
+
+        ctx.state = dict(N=N, T=T, D=D, H=H, HD=HD, F=F_, V=V, ML=ML, nl=nl, R=R, layers=layers, B=B_, xout=xout, last=last, ys=ys,
+                         heads=heads, g_heads=(ops._gbuf(heads[0]), ops._gbuf(heads[1])), g_emb=ops._gbuf(emb), seed=seed,
+                         p_emb=p_emb, off_emb=off_emb, streams=streams, two=side is not None, enc2=enc2, training=training)
+        ctx.set_materialize_grads(False)
+        dec.last_ys = ys
+        # (ML*N, V) step-major -> (N, ML, V) views
+        return pred[0].view(ML, N, V).transpose(0, 1), pred[1].view(ML, N, V).transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, dpl, dpr):
+        S = ctx.state
+        call, gemm, segs = ops.call, ops.gemm, ops._segs
+        N, T, D, H, HD, F_, V, ML, nl, R = (S[k] for k in ("N", "T", "D", "H", "HD", "F", "V", "ML", "nl", "R"))
+        layers, B_, streams = S["layers"], S["B"], S["streams"]
+        main, side = streams[0], (streams[1] if S["two"] else None)
+        dev = S["enc2"].device
+        seed = S["seed"]
+        segL = tuple(range(1, ML + 1))
+        seg_arr, nseg = segs(segL)
+        seg_lo, seg_hi = segs(segL[:8]), segs(segL[8:])
+        R8 = N * 36                                    # rows of the first 8 segments (prefix lengths 1..8)
+        pe8 = H * N * T * 36                           # their cross-attention probabilities
+
+        def E(*shape):
+            return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+        wg = []                                        # deferred weight gradients: (C, ldc, colsum, A, lda, B, ldb, M, N)
+
+        def dW(C, colsum, A, lda, Bm, ldb, M, Nn):
+            wg.append((C, Nn, colsum, A, lda, Bm, ldb, M, Nn))
+
+        if side is not None:
+            side.wait_stream(main)
+        # ---- heads and the gather of the last positions
+        dx = [None, None]
+        for d, dp in ((0, dpl), (1, dpr)):
+            with torch.cuda.stream(streams[d]):
+                if dp is None:
+                    dx[d] = torch.zeros(R, D, device=dev, dtype=torch.float32)
+                    continue
+                dpred = dp.transpose(0, 1).contiguous().view(ML * N, V)
+                dlast = E(ML * N, D)
+                gemm(0, 0, ML * N, D, V, dpred, V, S["heads"][d], D, dlast, D)
+                gemm(1, 0, V, D, ML * N, dpred, V, S["last"][d], D, S["g_heads"][d], D, accumulate=1)
+                dx[d] = E(R, D)
+                call("sbl_gather_last_bwd", _p(dlast), _p(dx[d]), N, seg_arr, nseg, D, ops._s())
+
+        def ln_bwd(dy, o, res, ln, mu, rs, drop_p, off):
+            g, _, gg, gb, _ = ln
+            dz = E(R, D)
+            do = E(R, D)          # separate: the deferred weight gradient reads it after dz has been accumulated into
+            call("sbl_add_layernorm_bwd", _p(dy), _p(o), _p(res), _p(g), _p(mu), _p(rs), _p(dz), _p(do), _p(gg), _p(gb), R, D, drop_p,
+                 _p(seed) if drop_p > 0 else None, off, ops._s())
+            return dz, do
+
+        keep = []                                      # operands of the deferred weight gradients stay alive until the flush
+        dkv_all = [[None] * nl for _ in (0, 1)]
+
+        def layer_bwd(d, n, dy):
+            L, b = layers[d][n], B_[d][n]
+            # feed-forward
+            dz, do = ln_bwd(dy, b["o_f"], b["y_e"], L.ln_f, b["mu_f"], b["rs_f"], L.drop_f, b["off"][4])
+            dW(L.g_w2, L.g_b2, do, D, b["h"], F_, D, F_)
+            dh = E(R, F_)
+            gemm(0, 0, R, F_, D, do, D, L.w2, F_, dh, F_, mask=b["h"], ldm=F_)
+            dW(L.g_w1, L.g_b1, dh, F_, b["y_e"], D, F_, D)
+            gemm(0, 0, R, D, F_, dh, F_, L.w1, D, dz, D, accumulate=1)
+            keep.extend((do, dh))
+            # cross-attention
+            dz2, do2 = ln_bwd(dz, b["o_e"], b["y_s"], L.ln_e, b["mu_e"], b["rs_e"], L.drop_e, b["off"][3])
+            dW(L.g_wfc_e, L.g_bfc_e, do2, D, b["att2"], HD, D, HD)
+            datt = E(R, HD)
+            gemm(0, 0, R, HD, D, do2, D, L.wfc_e, HD, datt, HD)
+            dq = E(R, HD)
+            kv = b["kv"]
+            dkv_a, dkv_b = E(N * T, 2 * HD), E(N * T, 2 * HD)
+            # 16 segments share the keys: two launches of 8 (one workgroup per (batch, head) sums 8 segments in LDS)
+            for (arr, ns), r0, p0, dst in ((seg_lo, 0, 0, dkv_a), (seg_hi, R8, pe8, dkv_b)):
+                rows = slice(r0, R8 if r0 == 0 else R)
+                call("sbl_attention_seg_bwd", _p(datt[rows]), HD, _p(b["q"][rows]), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD,
+                     b["pe"].data_ptr() + 4 * p0, _p(dq[rows]), HD, _p(dst), 2 * HD, _p(dst[:, HD:]), 2 * HD, N, H, arr, ns, T, 0.125,
+                     L.drop_e, _p(seed) if L.drop_e > 0 else None, _fold(b["off"][2], p0), ops._s())
+            dkv_a.add_(dkv_b)
+            dkv_all[d][n] = dkv_a
+            dW(L.g_wq, L.g_bq, dq, HD, b["y_s"], D, HD, D)
+            gemm(0, 0, R, D, HD, dq, HD, L.wq, D, dz2, D, accumulate=1)
+            keep.extend((do2, dq))
+            # self-attention
+            dz3, do3 = ln_bwd(dz2, b["o_s"], b["x"], L.ln_s, b["mu_s"], b["rs_s"], L.drop_s, b["off"][1])
+            dW(L.g_wfc_s, L.g_bfc_s, do3, D, b["att"], HD, D, HD)
+            datt = E(R, HD)
+            gemm(0, 0, R, HD, D, do3, D, L.wfc_s, HD, datt, HD)
+            dqkv = E(R, 3 * HD)
+            qkv = b["qkv"]
+            call("sbl_attention_seg_bwd", _p(datt), HD, _p(qkv), 3 * HD, _p(qkv[:, HD:]), 3 * HD, _p(qkv[:, 2 * HD:]), 3 * HD, _p(b["ps"]),
+                 _p(dqkv), 3 * HD, _p(dqkv[:, HD:]), 3 * HD, _p(dqkv[:, 2 * HD:]), 3 * HD, N, H, seg_arr, nseg, 0, 0.125, L.drop_s,
+                 _p(seed) if L.drop_s > 0 else None, b["off"][0], ops._s())
+            dW(L.g_wqkv, L.g_bqkv, dqkv, 3 * HD, b["x"], D, 3 * HD, D)
+            gemm(0, 0, R, D, 3 * HD, dqkv, 3 * HD, L.wqkv, D, dz3, D, accumulate=1)
+            keep.extend((do3, dqkv))
+            return dz3
+
+        for n in range(nl - 1, -1, -1):
+            if side is not None:
+                main.wait_stream(side)
+            dy = [E(R, D), E(R, D)]
+            call("sbl_fusion_seg_bwd", _p(dx[0]), _p(dx[1]), _p(dy[0]), _p(dy[1]), N, seg_arr, nseg, D, ops._s())
+            if side is not None:
+                side.wait_stream(main)
+            for d in (0, 1):
+                with torch.cuda.stream(streams[d]):
+                    dx[d] = layer_bwd(d, n, dy[d])
+        # ---- embeddings (shared table: float atomics) and the hoisted K/V projections
+        denc = [E(N * T, D), E(N * T, D)]
+        for d in (0, 1):
+            with torch.cuda.stream(streams[d]):
+                g = dx[d]
+                if S["p_emb"] > 0:
+                    g2 = E(R, D)
+                    call("sbl_dropout", _p(g), _p(g2), R * D, S["p_emb"], _p(seed), S["off_emb"][d], ops._s())
+                    g = g2
+                call("sbl_embed_seg_bwd", _p(S["ys"][d]), S["ys"][d].stride(0), _p(g), _p(S["g_emb"]), N, seg_arr, nseg, D, V, ops._s())
+                for n in range(nl):
+                    L = layers[d][n]
+                    dkv = dkv_all[d][n]
+                    gemm(0, 0, N * T, D, 2 * HD, dkv, 2 * HD, L.wkv, D, denc[d], D, accumulate=1 if n else 0)
+                    wg.append((L.g_wkv, D, L.g_bkv, dkv, 2 * HD, S["enc2"], D, 2 * HD, D))   # rows = N*T: its own group
+        if side is not None:
+            main.wait_stream(side)
+        denc[0].add_(denc[1])
+        # ---- every weight gradient of the decoder: one grouped launch per row count (R rows; N*T rows for K/V)
+        _flush_weight_grads(wg, {id(L.g_wkv): N * T for d in (0, 1) for L in layers[d]}, R, main, side)
+        ctx.state = None
+        return denc[0].view(N, T, D), None, None, None, None, None
+
+
+def _flush_weight_grads(wg, rows_of, R, main, side):
+    """C (+)= A^T B for every collected (C, ldc, colsum, A, lda, B, ldb, M, N); grouped launches (one per distinct row
+    count) on the side stream when the rows are a multiple of 16, per-weight split-K GEMMs otherwise."""
+    import ctypes as ct
+    run = side if (side is not None and ops.FLUSH_ON_SIDE) else main
+    if run is not main:
+        run.wait_stream(main)
+    groups = {}
+    for e in wg:
+        groups.setdefault(rows_of.get(id(e[0]), R), []).append(e)
+    with torch.cuda.stream(run):
+        for rows, ents in groups.items():
+            if ops.GROUP_WGRAD and rows % 16 == 0 and len(ents) > 1:
+                n = len(ents)
+                need = ops._lib.load().sbl_wgrad_group_table_bytes(n)
+                key = (run.device_index, run.cuda_stream, "stages", rows)
+                tab = ops._group_tables.get(key)
+                if tab is None or tab.numel() < need:
+                    tab = ops._group_tables[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=torch.device("cuda", run.device_index))
+                ops.call("sbl_wgrad_group_f32", n, 1, (ct.c_int * 1)(rows), (ct.c_void_p * n)(*[e[3].data_ptr() for e in ents]),
+                         (ct.c_long * n)(*[e[4] for e in ents]), (ct.c_void_p * n)(*[e[5].data_ptr() for e in ents]),
+                         (ct.c_long * n)(*[e[6] for e in ents]), (ct.c_int * n)(*[e[7] for e in ents]), (ct.c_int * n)(*[e[8] for e in ents]),
+                         (ct.c_void_p * n)(*[e[0].data_ptr() for e in ents]), (ct.c_long * n)(*[e[1] for e in ents]),
+                         (ct.c_void_p * n)(*[_p(e[2]) for e in ents]), tab.data_ptr(), tab.numel(), ops._s())
+            else:
+                for (C, ldc, colsum, A, lda, Bm, ldb, M, Nn) in ents:
+                    ops.gemm(1, 0, M, Nn, rows, A, lda, Bm, ldb, C, ldc, accumulate=1, colsum=colsum)
+            for e in ents:
+                e[3].record_stream(run)
+                e[5].record_stream(run)
+    if run is not main:
+        main.wait_stream(run)

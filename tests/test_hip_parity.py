@@ -715,6 +715,93 @@ def test_config5_shape_matches_oracle(ops):
             assert rel < 5e-3, (n, rel)
 
 
+@pytest.mark.parametrize("B,two", [(16, True), (3, True), (4, False)])
+def test_stage_batched_decoder_backward_equals_per_stage_tape(ops, B, two):
+    """decoder_stages.DecoderStagesFn (forward per stage into all-step buffers with raw kernels, ONE backward batched
+    over all 16 steps) against the per-stage autograd tape of Decoder._run: same logits, loss and gradients.
+    B = 16: grouped weight-gradient launch; B = 3 / 4: row counts that are not multiples of 16 (per-weight fallback)."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    T, H, W, ne, nd = 4, 24, 24, 1, 2
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 71)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    res = []
+    for fast in (False, True):
+        m = build_model(ne, nd).train()
+        m.decoder.batched_backward = fast
+        m.decoder.two_streams = two
+        flat = dp.FlatModel(m)
+        flat.zero_grad()
+        random.seed(17)
+        pl, gl, pr, gr = m(xd, ld, rd)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        res.append((pl.detach().clone(), pr.detach().clone(), float(loss.item()), flat.flat_grad.clone(), dict(flat.ranges),
+                    {n: p.grad.clone() for n, p in m.named_parameters()}, list(m.decoder.last_coins)))
+    assert res[0][6] == res[1][6] and 0 < sum(res[0][6]) < 16
+    assert maxdiff(res[1][0], res[0][0]) < 2e-5 and maxdiff(res[1][1], res[0][1]) < 2e-5 and abs(res[0][2] - res[1][2]) < 2e-5
+    for n, g in res[1][5].items():
+        ref = res[0][5][n]
+        if n.startswith("decoder") or n.startswith("encoder"):
+            assert maxdiff(g, ref) < 1e-3 * float(ref.abs().max()) + 2e-6, n
+    a, b = res[0][4]["visual_frontend."]
+    rel = float((res[1][3][a:b].double() - res[0][3][a:b].double()).norm() / res[0][3][a:b].double().norm())
+    assert rel < 3e-2, rel
+
+
+def test_stage_batched_decoder_dropout_masks_match_between_forward_and_backward(ops):
+    """With dropout ON the stage-batched backward regenerates every mask (embedding, attention probabilities, the three
+    sub-layer outputs) from whole-buffer indices while the forward drew them stage by stage with folded offsets.  For a
+    fixed seed the loss is a deterministic function of the parameters, so central differences along random directions
+    must match <gradient, direction>; a single mismatching mask would show as an O(1) relative error."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    B, T, H, W, ne, nd = 16, 4, 24, 24, 1, 2
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 73)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    m = build_model(ne, nd).train()
+    for mm in m.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.1
+    # every coin "teacher-forced": a sampled (argmax) token would make the loss discontinuous in the parameters; the
+    # stage loop and its mask offsets do not depend on the coins (the equality test above covers mixed coins at p=0)
+    m.decoder.coins_host = [False] * 16
+    flat = dp.FlatModel(m)
+    st = ops.dropout_state(torch.device(DEV))
+    with torch.no_grad():
+        feats = m.visual_frontend(xd.unsqueeze(4).permute(0, 4, 1, 2, 3))     # fixed features: only the transformer is probed
+    lengths = [T] * B
+
+    def loss_fn():
+        st._offset = 0                                   # same (seed, offsets) for every evaluation
+        enc, *_ = m.encoder(feats, lengths)
+        pl, gl, pr, gr = m.decoder(ld, rd, enc, lengths)
+        return 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+
+    flat.zero_grad()
+    loss_fn().backward()
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    grad = flat.flat_grad.clone()
+    a, b = flat.ranges["decoder."]
+    gen = torch.Generator(DEV).manual_seed(5)
+    for trial in range(3):
+        v = torch.zeros_like(flat.flat_param)
+        v[a:b] = torch.randn(b - a, device=DEV, generator=gen)
+        ana = float((grad.double() * v.double()).sum())
+        eps = 2e-4
+        base = flat.flat_param.clone()
+        vals = []
+        for sgn in (1.0, -1.0):
+            flat.flat_param.copy_(base + sgn * eps * v)
+            vals.append(float(loss_fn().detach().double()))      # grad mode stays on: same (stage-batched) code path
+        flat.flat_param.copy_(base)
+        num = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(num - ana) < 1.5e-2 * abs(ana) + 2e-2, (trial, num, ana)    # measured 0.3 %; a wrong mask gives O(1)
+
+
 @pytest.mark.parametrize("B", [3, 16])
 def test_flat_direct_accumulation_and_two_streams_match_plain_autograd(ops, B):
     """The throughput path (dp.FlatModel: kernels accumulate gradients straight into one flat buffer, the two
