@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--split-graph", choices=("auto", "on", "off"), default="auto",
                     help="capture the step as two hipGraphs (everything up to the encoder's input gradient | frontend backward) so "
                          "that the decoder + encoder gradient all-reduces overlap the frontend backward; auto = on when N > 1")
+    ap.add_argument("--dump-launches", default="", help="debug: write a per-shape table of the instrumented launches to this file")
     ap.add_argument("--hang-dump", type=int, default=0, help="debug: dump all Python stacks after this many seconds")
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     return ap.parse_args()
@@ -111,8 +112,10 @@ class LaunchRecorder:
                 return inner(name, *a)
             s0 = self.lib.sbl_profile_used()       # process-wide counter: backward runs on the autograd thread
             inner(name, *a)
+            desc = name
             if name == "sbl_gemm_f32":
                 fl = 2.0 * a[2] * a[3] * a[4]
+                desc = "gemm ta%d tb%d M%d N%d K%d" % (a[0], a[1], a[2], a[3], a[4])
             elif name == "sbl_wgrad_seg_f32":      # merged decoder weight gradient: contracts over all stages' rows
                 fl = 2.0 * a[6] * a[7] * sum(a[5][i] for i in range(a[0]))
             elif name == "sbl_wgrad_group_f32":    # every deferred weight gradient in one launch
@@ -123,11 +126,12 @@ class LaunchRecorder:
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
                 ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
+                desc = "%s n%d %dx%d c%d->%d k%d s%d" % (name[4:], nimg, h, w, cin, cout, kh, stride)
             else:
                 return
             s1 = self.lib.sbl_profile_used()
             if s1 > s0:      # a call may make several launches (stride-2 input gradients: one per parity class)
-                self.launches.append((tuple(range(s0, s1)), self.lib.sbl_profile_last_kernel(), fl))
+                self.launches.append((tuple(range(s0, s1)), self.lib.sbl_profile_last_kernel(), fl, desc))
         ops.call = call
 
 
@@ -364,28 +368,37 @@ def main():
                     fwd_bwd()
             run()
         rec.active = False
+        torch.cuda.synchronize()
         used = lib.sbl_profile_end()
-        launches = [l for l in rec.launches if l[0][-1] < used] if graph is not None else rec.launches
-        reps = 3
-        dur = np.zeros(CAP)
-        for _ in range(reps):
-            stamps.copy_(init)
-            torch.cuda.synchronize()
-            if graph is not None:
+        launches = [l for l in rec.launches if l[0][-1] < used]
+        if graph is not None:
+            reps = 3
+            dur = np.zeros(CAP)
+            for _ in range(reps):
+                stamps.copy_(init)
+                torch.cuda.synchronize()
                 run()
-            else:
-                lib.sbl_profile_begin(stamps.data_ptr(), CAP)
-                run()
-                lib.sbl_profile_end()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                s = stamps.cpu().numpy()
+                dur += (s[:, 1] - s[:, 0]) / 100.0        # 100 MHz ticks -> microseconds
+            dur /= reps
+        else:
+            # eager: the stamps of the recorded pass itself (slot order is only defined within one pass)
             s = stamps.cpu().numpy()
-            dur += (s[:, 1] - s[:, 0]) / 100.0            # 100 MHz ticks -> microseconds
-        dur /= reps
-        for slots, kid, fl in launches:
+            dur = (s[:, 1] - s[:, 0]) / 100.0
+        for slots, kid, fl, _d in launches:
             f = fam.setdefault(kid, {"launches": 0, "us": 0.0, "flops": 0.0})
             f["launches"] += len(slots)
             f["us"] += float(sum(dur[sl] for sl in slots))
             f["flops"] += fl
+        if args.dump_launches:
+            agg = {}
+            for slots, kid, fl, d in launches:
+                e = agg.setdefault((kid, d), [0, 0.0, 0.0])
+                e[0] += 1; e[1] += float(sum(dur[sl] for sl in slots)); e[2] += fl
+            with open(args.dump_launches, "w") as f:
+                for (kid, d), (n, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write("%8.1f us  n=%3d  avg %7.1f us  %6.1f TF  kid %d  %s\n" % (us, n, us / n, fl / us / 1e6, kid, d))
         log(args, "kernel timing done (%d instrumented launches per step)" % len(launches))
 
     if rank == 0:
