@@ -15,6 +15,11 @@ static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout
 }
 static inline int out_dim(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
 
+// Position-major path for 3x3 / stride-1 convolutions on small maps (ResNet layers 3, 4): SBL_CONV_PM_HW = largest
+// Ho*Wo that takes it (0 = off; A/B knob)
+static const int g_pm_hw = getenv("SBL_CONV_PM_HW") ? atoi(getenv("SBL_CONV_PM_HW")) : 36;
+static inline bool conv_pm_ok(int Ho, int Wo, int KH, int stride) { return KH == 3 && stride == 1 && Ho * Wo <= g_pm_hw; }
+
 #define SBL_CONV_WS_COUNTERS 4096      // same workspace convention as sbl_gemm_f32: int counters, then fp32 slabs
 static const int g_tailsplit = getenv("SBL_CONV_TAILSPLIT") ? atoi(getenv("SBL_CONV_TAILSPLIT")) : 1;   // A/B knob
 
@@ -47,6 +52,29 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
+    if (conv_pm_ok(Ho, Wo, KH, stride)) {
+        // position-major rows: border pixels skip their out-of-bounds taps (mfma_gemm.h, ConvGatherPM)
+#define SBL_CONV_FWD_PM(BM, BN)                                                                                \
+    do {                                                                                                       \
+        ConvGatherPM<BM, false> al{x, g, M, 0ull};                                                             \
+        DenseKCTapList<BN> bl{w, (long)K, N, Cin, 0ull};                                                       \
+        SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};                         \
+        dim3 grid(SBL_PM_NFAST ? sbl_cdiv(N, BN) : sbl_cdiv(M, BM), SBL_PM_NFAST ? sbl_cdiv(M, BM) : sbl_cdiv(N, BN), 1); \
+        if (stats) {                                                                                           \
+            EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0, 2, NIMG, Ho * Wo, 0, 0, 0, 0};      \
+            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, false>, DenseKCTapList<BN>, EpiStore<0, true>, BM, BN, false>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+        } else {                                                                                               \
+            EpiStore<0, false> e{y, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, Ho * Wo, 0, 0, 0, 0};   \
+            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, false>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, false>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+        }                                                                                                      \
+    } while (0)
+        if (N >= 128 && t128 >= 512) SBL_CONV_FWD_PM(128, 128);
+        else if ((long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_FWD_PM(128, 64);
+        else SBL_CONV_FWD_PM(64, 64);
+#undef SBL_CONV_FWD_PM
+        SBL_LAUNCH_CHECK("sbl_conv2d_fwd(pm)");
+        return 0;
+    }
     // all tiles are co-resident (<= 4 workgroups per CU), so the launch lasts as long as the fullest CU: pick the
     // largest tile whose count per CU (256 CUs) does not round up by more than ~20 % (522 128x128 tiles = 2.04/CU
     // would run at 3/CU speed; 1044 128x64 tiles = 4.08/CU at 5/CU)
@@ -107,6 +135,23 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
     ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_dgrad: workspace unaligned or < 16 KiB");
+    if (conv_pm_ok(H, W, KH, stride)) {
+#define SBL_CONV_DG_PM(BM, BN)                                                                                 \
+    do {                                                                                                       \
+        ConvGatherPM<BM, true> al{dy, g, M, 0ull};                                                             \
+        DenseKCTapList<BN> bl{wt, (long)K, N, Cout, 0ull};                                                     \
+        SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                       \
+        dim3 grid(SBL_PM_NFAST ? sbl_cdiv(N, BN) : sbl_cdiv(M, BM), SBL_PM_NFAST ? sbl_cdiv(M, BM) : sbl_cdiv(N, BN), 1); \
+        EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};        \
+        hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+    } while (0)
+        if (N >= 128 && t128 >= 512) SBL_CONV_DG_PM(128, 128);
+        else if ((long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG_PM(128, 64);
+        else SBL_CONV_DG_PM(64, 64);
+#undef SBL_CONV_DG_PM
+        SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(pm)");
+        return 0;
+    }
 #define SBL_CONV_DG(BM, BN, WN)                                                                               \
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
@@ -156,6 +201,20 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
         EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
         sbl_launch_gemm<DenseMC<BM, true>, ConvGatherMC<BN>, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s, sc); \
     } while (0)
+    if (conv_pm_ok(Ho, Wo, KH, stride) && big && M >= 128 && Cin % 128 == 0) {
+        // one tap per 128-wide tile of the (tap, ci) axis: contract only over the pixels that tap can reach
+        const long tiles = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+        int splits = (int)((wg_target + tiles - 1) / tiles);
+        if (splits > K / 256) splits = K / 256;
+        if (splits < 1) splits = 1;
+        DenseMCPM<128> al{dy, (long)Cout, M, NIMG, Ho, Wo, PmRect{0, 0, 1, 0, 0}};
+        ConvGatherMCPM<128> bl{x, g, N, PmRect{0, 0, 1, 0, 0}};
+        EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};
+        hipLaunchKernelGGL((sbl_conv_pm_wgrad_kernel<DenseMCPM<128>, ConvGatherMCPM<128>, EpiStore<2, false>, 128, 128>),
+                           dim3(sbl_cdiv(M, 128), sbl_cdiv(N, 128), splits), dim3(256), 0, s, al, bl, e, sc, M, N);
+        SBL_LAUNCH_CHECK("sbl_conv2d_wgrad(pm)");
+        return 0;
+    }
     if (big && M >= 128) SBL_CONV_WG(128, 128);
     else SBL_CONV_WG(64, 64);
 #undef SBL_CONV_WG

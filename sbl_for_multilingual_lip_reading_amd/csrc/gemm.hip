@@ -120,7 +120,7 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
     int mode = accumulate ? 1 : 0;
     if (splits > 1) {
         const long need = (long)sizeof(int) * SBL_WS_COUNTERS + tiles64 * splits * (long)(64 * 64 * sizeof(float));
-        if (ws && tiles64 <= SBL_WS_COUNTERS && need <= ws_bytes) {
+        if (ws && tiles64 < SBL_WS_COUNTERS && need <= ws_bytes) {   // (the last counter belongs to conv.hip's persistent kernels)
             sc.counters = (int*)ws;                                     // in-launch slab reduction, full epilogue
             sc.slabs = (float*)((char*)ws + sizeof(int) * SBL_WS_COUNTERS);
         } else if (plain) {

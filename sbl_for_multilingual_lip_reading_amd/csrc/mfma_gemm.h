@@ -134,6 +134,58 @@ struct DenseKCTaps {
     }
 };
 
+// Same, with the block list packed 4 bits per entry (up to 9 blocks) and set per workgroup: the weight operand of the
+// position-major convolutions below, whose tiles contract only over the taps that can be in bounds for their pixels.
+template <int BR>
+struct DenseKCTapList {
+    static constexpr bool kColSum = false;
+    const float* p;
+    long ld;
+    int rows;
+    int C;
+    unsigned long long taps;
+    struct State {
+        const float* rp[BR / 64];
+        bool ok[BR / 64];
+        int kq;
+    };
+    struct Regs {
+        float4 v[BR / 64];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.kq = (tid & 3) * 4;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            int r = r0 + ps * 64 + (tid >> 2);
+            s.ok[ps] = r < rows;
+            s.rp[ps] = p + (long)(s.ok[ps] ? r : 0) * ld;
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+        const int t = k0 / C;              // block-uniform
+        const int l = (int)((taps >> (4 * t)) & 15ull);
+        const int k = l * C + (k0 - t * C) + s.kq;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s.ok[ps] && k0 < kend) v = *reinterpret_cast<const float4*>(s.rp[ps] + k);
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            const int row = ps * 64 + (tid >> 2);
+            lds[s.kq + 0][row] = r.v[ps].x;
+            lds[s.kq + 1][row] = r.v[ps].y;
+            lds[s.kq + 2][row] = r.v[ps].z;
+            lds[s.kq + 3][row] = r.v[ps].w;
+        }
+    }
+};
+
 // Dense, m-contiguous: element (r,k) at p[k*ld + r].  Used for dY^T / X in weight-gradient
 // GEMMs and for W[K,N] in input-gradient GEMMs.
 template <int BR, bool VEC>
@@ -412,6 +464,161 @@ struct ConvGatherMC {
     }
 };
 
+// ---- position-major 3x3 / stride-1 convolutions on small maps (ResNet layers 3 and 4: 6x6 and 3x3 pixels).
+// With pad 1 a border pixel sees only 4 or 6 of the 9 taps; on a 3x3 map 40 % (6x6: 21 %) of the im2col matrix is
+// zero padding.  Ordering the GEMM rows position-major (row = pos * NIMG + img) makes the set of in-bounds taps
+// (nearly) uniform per tile, so each workgroup contracts only over the taps its positions can reach; products with
+// the padded zeros are skipped, every kept product is the same as before (bit-identical accumulation order per tap).
+template <int BR, bool DGRAD>
+struct ConvGatherPM {
+    static constexpr bool kColSum = false;
+    const float* p;
+    ConvGeom g;
+    int rows;   // NIMG*OH*OW
+    unsigned long long taps;   // the workgroup's tap list, 4 bits each (set by sbl_conv_pm_kernel)
+    struct State {
+        int img[BR / 64], oh[BR / 64], ow[BR / 64];
+        bool ok[BR / 64];
+        int kq;
+    };
+    struct Regs {
+        float4 v[BR / 64];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.kq = (tid & 3) * 4;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            int r = r0 + ps * 64 + (tid >> 2);
+            s.ok[ps] = r < rows;
+            if (!s.ok[ps]) r = 0;
+            const int pos = r / g.NIMG;
+            s.img[ps] = r - pos * g.NIMG;
+            s.oh[ps] = pos / g.OW;
+            s.ow[ps] = pos - s.oh[ps] * g.OW;
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+        const int t = k0 / g.C;            // block-uniform
+        const int tap = (int)((taps >> (4 * t)) & 15ull);
+        const int c = k0 - t * g.C + s.kq;
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int ih, iw;
+            if (s.ok[ps] && k0 < kend && conv_src_coord<DGRAD>(g, s.oh[ps], s.ow[ps], kh, kw, ih, iw))
+                v = *reinterpret_cast<const float4*>(p + (((long)s.img[ps] * g.SH + ih) * g.SW + iw) * g.C + c);
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            const int row = ps * 64 + (tid >> 2);
+            lds[s.kq + 0][row] = r.v[ps].x;
+            lds[s.kq + 1][row] = r.v[ps].y;
+            lds[s.kq + 2][row] = r.v[ps].z;
+            lds[s.kq + 3][row] = r.v[ps].w;
+        }
+    }
+};
+
+// Weight gradient, position-major: a tile of the (tap, ci) axis that lies inside ONE tap contracts only over the
+// output pixels for which that tap is in bounds - a rectangle [oh_lo, oh_lo+nh) x [ow_lo, ow_lo+nw) of the map, all
+// images: GEMM-k' = vp * NIMG + img with vp the index inside the rectangle.  PmRect is set per workgroup.
+struct PmRect {
+    int oh_lo, ow_lo, nw, dh, dw;    // source pixel = (oh + dh, ow + dw), always in bounds inside the rectangle
+};
+template <int BR>
+struct DenseMCPM {            // dY^T: element (co, k') = dy[pixel(k')][co]
+    static constexpr bool kColSum = false;
+    const float* p;
+    long ld;
+    int rows;
+    int NIMG, OH, OW;
+    PmRect rc;
+    static constexpr int TPR = BR / 4;
+    static constexpr int RPP = 256 / TPR;
+    static constexpr int NP = SBL_BK / RPP;
+    struct State {
+        int c, kr;
+    };
+    struct Regs {
+        float4 v[NP];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        s.c = r0 + (tid % TPR) * 4;
+        s.kr = tid / TPR;
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int k = k0 + s.kr + ps * RPP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend && s.c < rows) {
+                const int vp = k / NIMG, img = k - vp * NIMG;
+                const int a = vp / rc.nw, b = vp - a * rc.nw;
+                v = *reinterpret_cast<const float4*>(p + (((long)img * OH + rc.oh_lo + a) * OW + rc.ow_lo + b) * ld + s.c);
+            }
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State& s) const { return s.c; }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
+    }
+};
+template <int BR>
+struct ConvGatherMCPM {       // x gathered: element ((tap, ci), k') = x[img, oh + dh, ow + dw, ci]
+    static constexpr bool kColSum = false;
+    const float* p;
+    ConvGeom g;
+    int rows;   // KH*KW*C
+    PmRect rc;
+    static constexpr int TPR = BR / 4;
+    static constexpr int RPP = 256 / TPR;
+    static constexpr int NP = SBL_BK / RPP;
+    struct State {
+        int c, kr;
+        bool ok;
+    };
+    struct Regs {
+        float4 v[NP];
+    };
+    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
+        int r = r0 + (tid % TPR) * 4;
+        s.ok = r < rows;
+        if (!s.ok) r = 0;
+        s.c = r % g.C;
+        s.kr = tid / TPR;
+    }
+    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int k = k0 + s.kr + ps * RPP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s.ok && k < kend) {
+                const int vp = k / g.NIMG, img = k - vp * g.NIMG;
+                const int a = vp / rc.nw, b = vp - a * rc.nw;
+                v = *reinterpret_cast<const float4*>(p + (((long)img * g.SH + rc.oh_lo + a + rc.dh) * g.SW + rc.ow_lo + b + rc.dw) * g.C + s.c);
+            }
+            r.v[ps] = v;
+        }
+    }
+    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
+    __device__ __forceinline__ int col(const State&) const { return 0; }
+    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
+    }
+};
+
 // ------------------------------------------------------------------ epilogues
 // MODE 0: C = acc (+bias) (ReLU)   MODE 1: C += acc (non-atomic; one block per tile)
 // MODE 2: atomicAdd(C, acc) (split-K; C pre-zeroed or accumulating)
@@ -426,10 +633,15 @@ struct EpiStore {
     const float* relu_mask;   // multiply by (mask[m*ldm+n] > 0) (ReLU backward) or nullptr
     long ldm;
     // optional output row map for the parity-class input gradients: GEMM row m = (img, a, b) of the class sub-grid
-    // (ca x cb) is pixel (2a + ph, 2b + pw) of the (cH x cW) image; cmap == 0: row m is output row m
+    // (ca x cb) is pixel (2a + ph, 2b + pw) of the (cH x cW) image; cmap == 0: row m is output row m;
+    // cmap == 2 (position-major rows): GEMM row m = pos * ca + img is output row img * cb + pos
     int cmap, ca, cb, cH, cW, cph, cpw;
     __device__ __forceinline__ long row_off(int m) const {
         if (!cmap) return (long)m * ldc;
+        if (cmap == 2) {
+            const int pos = m / ca;
+            return ((long)(m - pos * ca) * cb + pos) * ldc;
+        }
         const int img = m / (ca * cb);
         const int rem = m - img * (ca * cb);
         const int a = rem / cb, b = rem - a * cb;
@@ -658,6 +870,69 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
     sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, (blockIdx.x + x_off) * BM, blockIdx.y * BN, kbeg,
                                                min(K, kbeg + kchunk), blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, gridDim.z,
                                                blockIdx.y == 0);
+}
+
+// Position-major convolution tiles (ConvGatherPM x DenseKCTapList): the workgroup's tap list = union of the in-bounds
+// taps of the (at most two, when NIMG >= BM) positions its rows cover.
+#ifndef SBL_PM_NFAST
+#define SBL_PM_NFAST 1
+#endif
+template <bool DGRAD>
+__device__ __forceinline__ unsigned sbl_pm_tap_mask(const ConvGeom& g, int pos) {
+    const int oh = pos / g.OW, ow = pos - oh * g.OW;
+    unsigned m = 0;
+    for (int kh = 0; kh < g.KH; ++kh)
+        for (int kw = 0; kw < g.KW; ++kw) {
+            int ih, iw;
+            if (conv_src_coord<DGRAD>(g, oh, ow, kh, kw, ih, iw)) m |= 1u << (kh * g.KW + kw);
+        }
+    return m;
+}
+// (Measured and not kept: a persistent grid drawing tiles from an atomic counter to balance the 4 / 6 / 9-tap tiles.
+// With only 1-2 tiles per resident workgroup the per-slot quantisation costs more than the balance gains: layer 3
+// forward 360 -> 454 us, layer 4 390 -> 411 us.)
+template <class AL, class BL, class EPI, int BM, int BN, bool DGRAD>
+__global__ __launch_bounds__(256) void sbl_conv_pm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N) {
+    const int m0 = (SBL_PM_NFAST ? blockIdx.y : blockIdx.x) * BM;
+    const int p_lo = m0 / al.g.NIMG, p_hi = (min(m0 + BM, M) - 1) / al.g.NIMG;
+    unsigned mask = 0;
+    for (int ps = p_lo; ps <= p_hi; ++ps) mask |= sbl_pm_tap_mask<DGRAD>(al.g, ps);
+    unsigned long long list = 0;
+    int nt = 0;
+    for (int t = 0; t < al.g.KH * al.g.KW; ++t)
+        if ((mask >> t) & 1u) {
+            list |= (unsigned long long)t << (4 * nt);
+            ++nt;
+        }
+    al.taps = list;
+    bl.taps = list;
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, m0, (SBL_PM_NFAST ? blockIdx.x : blockIdx.y) * BN, 0, nt * al.g.C,
+                                             blockIdx.y * gridDim.x + blockIdx.x, 0, 1, false);
+}
+// Position-major weight-gradient tiles (DenseMCPM x ConvGatherMCPM, C % BN == 0: one tap per tile); gridDim.z
+// workgroups share the tile's own K' = (in-bounds pixels of its tap) * NIMG evenly and add with float atomics.
+template <class AL, class BL, class EPI, int BM, int BN>
+__global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N) {
+    const ConvGeom& g = bl.g;
+    const int n0 = blockIdx.y * BN;
+    const int tap = n0 / g.C;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    PmRect rc;
+    rc.dh = kh - g.pad;
+    rc.dw = kw - g.pad;
+    rc.oh_lo = max(0, -rc.dh);
+    rc.ow_lo = max(0, -rc.dw);
+    const int nh = min(g.OH, g.SH - rc.dh) - rc.oh_lo;
+    rc.nw = min(g.OW, g.SW - rc.dw) - rc.ow_lo;
+    const int K = nh * rc.nw * g.NIMG;
+    const int per = (K + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kchunk = (per + SBL_BK - 1) / SBL_BK * SBL_BK;
+    const int kbeg = blockIdx.z * kchunk;
+    if (kbeg >= K) return;
+    al.rc = rc;
+    bl.rc = rc;
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, blockIdx.x * BM, n0, kbeg, min(K, kbeg + kchunk),
+                                             blockIdx.y * gridDim.x + blockIdx.x, 0, 1, false);
 }
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>
