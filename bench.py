@@ -272,39 +272,49 @@ def main():
     use_split = args.workload == "full" and not args.no_graph and (args.split_graph == "on" or (args.split_graph == "auto" and world > 1))
     graph = None
     graphs = []
+    # With a process group alive other threads (collective watchdog) may touch the runtime while this thread captures:
+    # only this thread's calls are checked then.  Backward's launches come from the autograd thread either way.
+    cap_mode = "thread_local" if world > 1 else "global"
+
+    def capture(fn, pool=None):
+        if os.environ.get("SBL_BENCH_FAIL_CAPTURE"):      # test knob for the eager fallback below
+            raise RuntimeError("capture failure forced by SBL_BENCH_FAIL_CAPTURE")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, stream=cap_stream, capture_error_mode=cap_mode):
+            fn()
+        return g
+
     if not args.no_graph:
-        for i in range(len(patterns)):
-            set_coins(i)
-            if use_split:
-                try:
-                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(ga, stream=cap_stream):
-                        part_a()
-                    with torch.cuda.graph(gb, pool=ga.pool(), stream=cap_stream):      # reads part A's saved activations
-                        part_b()
-                    graphs.append((ga, gb))
-                    continue
-                except Exception as e:      # keep the run alive: one graph per step, exchange after the replay
-                    print("[bench] two-graph capture failed (%s: %s); falling back to one graph per step" % (type(e).__name__, e),
-                          file=sys.stderr, flush=True)
-                    split.clear()
-                    use_split = False
-                    graphs = []
-                    torch.cuda.synchronize()
-                    for j in range(i):      # re-capture the earlier patterns as single graphs
-                        set_coins(j)
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, stream=cap_stream):
-                            fwd_bwd()
-                        graphs.append(g)
-                    set_coins(i)
-            if True:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap_stream):
-                    fwd_bwd()
-                graphs.append(g)
-        graph = graphs[0]
-        log(args, "capture + instantiate done (%d coin patterns%s)" % (len(graphs), ", two graphs per step" if use_split else ""))
+        try:
+            for i in range(len(patterns)):
+                set_coins(i)
+                if use_split:
+                    try:
+                        ga = capture(part_a)
+                        gb = capture(part_b, pool=ga.pool())      # reads part A's saved activations
+                        graphs.append((ga, gb))
+                        continue
+                    except Exception as e:      # keep the run alive: one graph per step, exchange after the replay
+                        print("[bench] two-graph capture failed (%s: %s); falling back to one graph per step" % (type(e).__name__, e),
+                              file=sys.stderr, flush=True)
+                        split.clear()
+                        use_split = False
+                        graphs = []
+                        torch.cuda.synchronize()
+                        for j in range(i):      # re-capture the earlier patterns as single graphs
+                            set_coins(j)
+                            graphs.append(capture(fwd_bwd))
+                        set_coins(i)
+                graphs.append(capture(fwd_bwd))
+            graph = graphs[0]
+            log(args, "capture + instantiate done (%d coin patterns%s)" % (len(graphs), ", two graphs per step" if use_split else ""))
+        except Exception as e:
+            # last resort: the eager step (launch-bound by ~1 % only since the stage-batched decoder backward), with the
+            # gradient exchange launched from tensor hooks inside backward
+            print("[bench] graph capture failed (%s: %s); running the eager step" % (type(e).__name__, e), file=sys.stderr, flush=True)
+            split.clear()
+            graph, graphs, use_split = None, [], False
+            exchange = dp.GradientExchange(flat, world, overlap=True)
         torch.cuda.synchronize()
     step_no = [0]
 
@@ -354,6 +364,7 @@ def main():
         init = torch.zeros(CAP, 2, dtype=torch.int64, device=dev)
         init[:, 0] = -1                                   # as uint64: +inf for atomicMin
         stamps = init.clone()
+        exchange.world = 1          # rank 0 only from here on: no collectives (the eager fallback launches them from hooks)
         lib.sbl_profile_begin(stamps.data_ptr(), CAP)
         rec.active = True
         set_coins(0)
@@ -435,6 +446,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()               # rank 0's instrumented replays above: leave together
         dist.destroy_process_group()
 
 
