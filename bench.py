@@ -46,7 +46,32 @@ KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW,
                 5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
                 6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)",
                 7: "sbl_wgrad_group_kernel<SegMC,SegMC 128x128> (all deferred decoder / encoder weight grads, one launch each, no split-K)"}
+# kernel-name patterns of each family in the rocprofv3 --pmc summary (profiles/*_pmc_fetch_write_per_kernel.csv)
+KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm_kernel<Dense[KM]C<64, \w+>, Dense[KM]C<64, \w+>, EpiStore",
+                 3: r"sbl_mfma_gemm_kernel<Dense[KM]C<128, \w+>, Dense[KM]C<128, \w+>, EpiStore",
+                 4: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, false>",
+                 5: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, true>",
+                 6: r"(sbl_mfma_gemm_kernel<DenseMC<\d+, true>, ConvGatherMC|sbl_conv_pm_wgrad_kernel)", 7: r"sbl_wgrad_group_kernel"}
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_i_pmc_fetch_write_per_kernel.csv")
 T_START = time.perf_counter()
+
+
+def pmc_traffic(kid):
+    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE x 2 for gfx950's wide-read under-count + WRITE_SIZE; they cannot be collected from inside the process).
+    None when the summary is missing."""
+    import csv, re
+    try:
+        rows = list(csv.DictReader(open(PMC_SUMMARY)))
+    except OSError:
+        return None
+    n = b = 0.0
+    for r in rows:
+        if re.search(KERNEL_PMC_RE.get(kid, "$^"), r["kernel"]):
+            k = float(r["launches"])
+            n += k
+            b += k * 1024.0 * (float(r["avg_FETCH_SIZE_KB_x2_gfx950_wide_read_correction"]) + float(r["avg_WRITE_SIZE_KB"]))
+    return round(b / n) if n else None
 
 
 def parse():
@@ -115,23 +140,27 @@ class LaunchRecorder:
             desc = name
             if name == "sbl_gemm_f32":
                 fl = 2.0 * a[2] * a[3] * a[4]
+                by = 4.0 * (a[2] * a[4] + a[3] * a[4] + a[2] * a[3])
                 desc = "gemm ta%d tb%d M%d N%d K%d" % (a[0], a[1], a[2], a[3], a[4])
             elif name == "sbl_wgrad_seg_f32":      # merged decoder weight gradient: contracts over all stages' rows
                 fl = 2.0 * a[6] * a[7] * sum(a[5][i] for i in range(a[0]))
+                by = 4.0 * ((a[6] + a[7]) * sum(a[5][i] for i in range(a[0])) + 2 * a[6] * a[7])
             elif name == "sbl_wgrad_group_f32":    # every deferred weight gradient in one launch
                 rows = sum(a[2][i] for i in range(a[1]))
                 fl = sum(2.0 * a[7][p] * a[8][p] * rows for p in range(a[0]))
+                by = sum(4.0 * ((a[7][p] + a[8][p]) * rows + 2 * a[7][p] * a[8][p]) for p in range(a[0]))
             elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_wgrad"):
                 off = 1 if name == "sbl_conv2d_fwd" else 0
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
                 ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
+                by = 4.0 * (nimg * h * w * cin + nimg * ho * wo * cout + cout * kh * kw * cin)
                 desc = "%s n%d %dx%d c%d->%d k%d s%d" % (name[4:], nimg, h, w, cin, cout, kh, stride)
             else:
                 return
             s1 = self.lib.sbl_profile_used()
             if s1 > s0:      # a call may make several launches (stride-2 input gradients: one per parity class)
-                self.launches.append((tuple(range(s0, s1)), self.lib.sbl_profile_last_kernel(), fl, desc))
+                self.launches.append((tuple(range(s0, s1)), self.lib.sbl_profile_last_kernel(), fl, desc, by))
         ops.call = call
 
 
@@ -397,14 +426,15 @@ def main():
             # eager: the stamps of the recorded pass itself (slot order is only defined within one pass)
             s = stamps.cpu().numpy()
             dur = (s[:, 1] - s[:, 0]) / 100.0
-        for slots, kid, fl, _d in launches:
-            f = fam.setdefault(kid, {"launches": 0, "us": 0.0, "flops": 0.0})
+        for slots, kid, fl, _d, by in launches:
+            f = fam.setdefault(kid, {"launches": 0, "us": 0.0, "flops": 0.0, "bytes": 0.0})
+            f["bytes"] += by
             f["launches"] += len(slots)
             f["us"] += float(sum(dur[sl] for sl in slots))
             f["flops"] += fl
         if args.dump_launches:
             agg = {}
-            for slots, kid, fl, d in launches:
+            for slots, kid, fl, d, _by in launches:
                 e = agg.setdefault((kid, d), [0, 0.0, 0.0])
                 e[0] += 1; e[1] += float(sum(dur[sl] for sl in slots)); e[2] += fl
             with open(args.dump_launches, "w") as f:
@@ -431,15 +461,18 @@ def main():
             fams = []
             for kid, f in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
                 tf = f["flops"] / (f["us"] * 1e-6) / 1e12
-                fams.append({"kernel": KERNEL_NAMES.get(kid, str(kid)), "launches_per_step": f["launches"],
+                fams.append({"kid": kid, "bytes": f["bytes"], "kernel": KERNEL_NAMES.get(kid, str(kid)), "launches_per_step": f["launches"],
                              "ms_per_step": round(f["us"] / 1e3, 3), "avg_launch_us": round(f["us"] / f["launches"], 2),
                              "achieved_TFLOPs": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
             top = fams[0]
             out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved_TFLOPs"],
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_of_fp32_mfma_peak"],
-                               "traffic": None, "avg_launch_us": top["avg_launch_us"],
+                               "traffic": pmc_traffic(top["kid"]), "traffic_unit": "bytes/launch",
+                               "traffic_source": "profiles/" + os.path.basename(PMC_SUMMARY) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, eager)",
+                               "algorithmic_bytes_per_launch": round(top["bytes"] / top["launches_per_step"]),
+                               "avg_launch_us": top["avg_launch_us"],
                                "launches_per_step": top["launches_per_step"], "ms_per_step": top["ms_per_step"],
-                               "families": fams[1:]}
+                               "families": [{k: v for k, v in f.items() if k not in ("kid", "bytes")} for f in fams[1:]]}
         else:
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:

@@ -59,7 +59,7 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
         ConvGatherPM<BM, false> al{x, g, M, 0ull};                                                             \
         DenseKCTapList<BN> bl{w, (long)K, N, Cin, 0ull};                                                       \
         SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};                         \
-        dim3 grid(SBL_PM_NFAST ? sbl_cdiv(N, BN) : sbl_cdiv(M, BM), SBL_PM_NFAST ? sbl_cdiv(M, BM) : sbl_cdiv(N, BN), 1); \
+        dim3 grid(sbl_cdiv(N, BN), sbl_cdiv(M, BM), 1);                                                        \
         if (stats) {                                                                                           \
             EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0, 2, NIMG, Ho * Wo, 0, 0, 0, 0};      \
             hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, false>, DenseKCTapList<BN>, EpiStore<0, true>, BM, BN, false>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
@@ -141,7 +141,7 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
         ConvGatherPM<BM, true> al{dy, g, M, 0ull};                                                             \
         DenseKCTapList<BN> bl{wt, (long)K, N, Cout, 0ull};                                                     \
         SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                       \
-        dim3 grid(SBL_PM_NFAST ? sbl_cdiv(N, BN) : sbl_cdiv(M, BM), SBL_PM_NFAST ? sbl_cdiv(M, BM) : sbl_cdiv(N, BN), 1); \
+        dim3 grid(sbl_cdiv(N, BN), sbl_cdiv(M, BM), 1);                                                        \
         EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};        \
         hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
     } while (0)

@@ -863,20 +863,35 @@ __device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const 
     sbl_stamp_end(sc.stamp);
 }
 
+// XCD-aware tile order (x_off < 0 selects it; the real offset is then -x_off - 1).  Workgroups go to the 8 XCDs
+// round-robin by linear id, each XCD with its own L2.  With the plain (x fastest) order the n-tiles that share one
+// A row block land on different XCDs and every L2 fetches that block again.  Here XCD c works through a contiguous
+// range of the n-fastest tile order, so an A row block is fetched by one L2 and only the (small) B operand by all 8.
 template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2>
 __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
                                                             int kchunk, int x_off) {
-    const int kbeg = blockIdx.z * kchunk;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, (blockIdx.x + x_off) * BM, blockIdx.y * BN, kbeg,
-                                               min(K, kbeg + kchunk), blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, gridDim.z,
-                                               blockIdx.y == 0);
+    int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x_off < 0) {
+        // over the whole 3-D grid: the K-slices z of a weight-gradient launch share nothing, but the n-tiles of one
+        // slice read the same pixels (dY chunk, x chunk shifted by a tap), so (x, y) stay together inside z
+        const int X = gridDim.x, Y = gridDim.y, XY = X * Y, T = XY * gridDim.z;
+        const int id = (z * Y + y) * X + x, per = T >> 3, rem = T & 7;
+        const int c = id & 7, k = id >> 3;
+        const int t = (c < rem ? c * (per + 1) : rem * (per + 1) + (c - rem) * per) + k;
+        z = t / XY;
+        const int r = t - z * XY;
+        x = r / Y;
+        y = r - x * Y;
+        x_off = -x_off - 1;
+    }
+    const int kbeg = z * kchunk;
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, (x + x_off) * BM, y * BN, kbeg,
+                                               min(K, kbeg + kchunk), y * gridDim.x + x, z, gridDim.z, y == 0);
 }
+static const int g_xcd_swizzle = getenv("SBL_XCD_SWIZZLE") ? atoi(getenv("SBL_XCD_SWIZZLE")) : 1;   // A/B knob (same speed, 2.4x fewer fabric-side bytes: tools/bench_gemm7.py under --pmc FETCH_SIZE)
 
 // Position-major convolution tiles (ConvGatherPM x DenseKCTapList): the workgroup's tap list = union of the in-bounds
 // taps of the (at most two, when NIMG >= BM) positions its rows cover.
-#ifndef SBL_PM_NFAST
-#define SBL_PM_NFAST 1
-#endif
 template <bool DGRAD>
 __device__ __forceinline__ unsigned sbl_pm_tap_mask(const ConvGeom& g, int pos) {
     const int oh = pos / g.OW, ow = pos - oh * g.OW;
@@ -893,7 +908,10 @@ __device__ __forceinline__ unsigned sbl_pm_tap_mask(const ConvGeom& g, int pos) 
 // forward 360 -> 454 us, layer 4 390 -> 411 us.)
 template <class AL, class BL, class EPI, int BM, int BN, bool DGRAD>
 __global__ __launch_bounds__(256) void sbl_conv_pm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N) {
-    const int m0 = (SBL_PM_NFAST ? blockIdx.y : blockIdx.x) * BM;
+    // grid = (n-tiles, m-tiles), plain order.  (Measured and not kept: the XCD-aware order of sbl_mfma_gemm_kernel.  It
+    // hands each XCD a contiguous range of positions, i.e. mostly one tap count, and the 9-tap XCD then outlasts the
+    // others: layer 3 forward 362 -> 505 us although the fabric-side fetch halves.)
+    const int m0 = blockIdx.y * BM;
     const int p_lo = m0 / al.g.NIMG, p_hi = (min(m0 + BM, M) - 1) / al.g.NIMG;
     unsigned mask = 0;
     for (int ps = p_lo; ps <= p_hi; ++ps) mask |= sbl_pm_tap_mask<DGRAD>(al.g, ps);
@@ -906,7 +924,7 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_kernel(AL al, BL bl, EPI epi,
         }
     al.taps = list;
     bl.taps = list;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, m0, (SBL_PM_NFAST ? blockIdx.x : blockIdx.y) * BN, 0, nt * al.g.C,
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, m0, blockIdx.x * BN, 0, nt * al.g.C,
                                              blockIdx.y * gridDim.x + blockIdx.x, 0, 1, false);
 }
 // Position-major weight-gradient tiles (DenseMCPM x ConvGatherMCPM, C % BN == 0: one tap per tile); gridDim.z
@@ -914,7 +932,9 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_kernel(AL al, BL bl, EPI epi,
 template <class AL, class BL, class EPI, int BM, int BN>
 __global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N) {
     const ConvGeom& g = bl.g;
-    const int n0 = blockIdx.y * BN;
+    // (plain order: the XCD-aware order measured 4 % slower here - 384 -> 400 us on layer 3)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int n0 = by * BN;
     const int tap = n0 / g.C;
     const int kh = tap / g.KW, kw = tap - kh * g.KW;
     PmRect rc;
@@ -927,12 +947,12 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EP
     const int K = nh * rc.nw * g.NIMG;
     const int per = (K + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kchunk = (per + SBL_BK - 1) / SBL_BK * SBL_BK;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = bz * kchunk;
     if (kbeg >= K) return;
     al.rc = rc;
     bl.rc = rc;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, blockIdx.x * BM, n0, kbeg, min(K, kbeg + kchunk),
-                                             blockIdx.y * gridDim.x + blockIdx.x, 0, 1, false);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, bx * BM, n0, kbeg, min(K, kbeg + kchunk),
+                                             by * gridDim.x + bx, 0, 1, false);
 }
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>
@@ -942,7 +962,7 @@ static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, i
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk, 0);
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk, g_xcd_swizzle ? -1 : 0);
 }
 
 // Tail splitting.  Every tile of these launches is resident at once, so a launch lasts as long as its fullest CU:
@@ -967,10 +987,10 @@ static inline bool sbl_launch_gemm_tailsplit(const AL& al, const BL& bl, const E
     const long need = (long)sizeof(int) * ws_counters + rem * sp * (long)(BM * BN * sizeof(float));
     if (need > ws_bytes) return false;
     SplitCtl sa{nullptr, nullptr, nullptr, sbl_next_stamp_slot(stamp_kid)};
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(XA, Y, 1), dim3(256), 0, s, al, bl, epi, sa, M, N, K, K, 0);
+    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(XA, Y, 1), dim3(256), 0, s, al, bl, epi, sa, M, N, K, K, g_xcd_swizzle ? -1 : 0);
     SplitCtl sb{(float*)((char*)ws + sizeof(int) * ws_counters), (int*)ws, nullptr, sbl_next_stamp_slot(stamp_kid)};
     const int kchunk = sbl_cdiv(sbl_cdiv(K, sp), MK) * MK;
     hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(X - XA, Y, sbl_cdiv(K, kchunk)), dim3(256), 0, s, al, bl,
-                       epi, sb, M, N, K, kchunk, XA);
+                       epi, sb, M, N, K, kchunk, g_xcd_swizzle ? -(XA + 1) : XA);
     return true;
 }
