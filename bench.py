@@ -142,6 +142,10 @@ class LaunchRecorder:
                 fl = 2.0 * a[2] * a[3] * a[4]
                 by = 4.0 * (a[2] * a[4] + a[3] * a[4] + a[2] * a[3])
                 desc = "gemm ta%d tb%d M%d N%d K%d" % (a[0], a[1], a[2], a[3], a[4])
+            elif name == "sbl_gemm2_f32":          # both decoder directions in one launch
+                fl = 4.0 * a[0] * a[1] * a[2]
+                by = 8.0 * (a[0] * a[2] + a[1] * a[2] + a[0] * a[1])
+                desc = "gemm2 M%d N%d K%d" % (a[0], a[1], a[2])
             elif name == "sbl_wgrad_seg_f32":      # merged decoder weight gradient: contracts over all stages' rows
                 fl = 2.0 * a[6] * a[7] * sum(a[5][i] for i in range(a[0]))
                 by = 4.0 * ((a[6] + a[7]) * sum(a[5][i] for i in range(a[0])) + 2 * a[6] * a[7])

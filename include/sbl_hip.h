@@ -65,6 +65,13 @@ int sbl_profile_last_kernel(void);
 int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                  float* C, long ldc, const float* bias, int relu, const float* relu_mask, long ldm, int accumulate,
                  float* a_colsum, void* ws, long ws_bytes, sbl_stream_t stream);
+/* Two products of one shape in ONE launch: C_d[M,N] = A_d[M,K] * B_d[N,K]^T (+ bias_d) (ReLU), d = 0, 1 - the nn.Linear
+ * forward of layer_stack_l2r[i] and layer_stack_r2l[i], which SBL/transformer/decoder.py:121-156 runs back to back on
+ * same-shape inputs.  Kernel boundaries cost ~5 us and small launches on two streams do not overlap on this GPU, so
+ * the two decoder directions share launches.  Same kernels and workspace convention as sbl_gemm_f32. */
+int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* A1, long lda, const float* B0, const float* B1,
+                  long ldb, float* C0, float* C1, long ldc, const float* bias0, const float* bias1, int relu, void* ws,
+                  long ws_bytes, sbl_stream_t stream);
 /* Deferred weight gradient of one decoder weight over all stages of a step:
  * C[M,N] += sum_s A_s^T B_s with A_s (seg_rows[s] x M, row stride lda) = dY of stage s and B_s (seg_rows[s] x N) = its
  * input; a_colsum[m] += column sums of the A_s (bias gradient).  A_ptrs / B_ptrs / seg_rows are HOST arrays of nseg
@@ -161,6 +168,11 @@ int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream);
 int sbl_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                           float* mean, float* rstd, int M, int D, float eps, float drop_p, const uint64_t* seed,
                           uint64_t offset, sbl_stream_t stream);
+/* The same for two same-shape problems (the two decoder directions) in one launch. */
+int sbl_add_layernorm2_fwd(const float* x0, const float* x1, const float* res0, const float* res1, const float* gamma0,
+                           const float* gamma1, const float* beta0, const float* beta1, float* y0, float* y1, float* mean0,
+                           float* mean1, float* rstd0, float* rstd1, int M, int D, float eps, float drop_p,
+                           const uint64_t* seed, uint64_t offset0, uint64_t offset1, sbl_stream_t stream);
 /* dz = gradient of the LayerNorm input (= dres); dx_drop (may be NULL) = gradient of the pre-dropout x;
  * dgamma/dbeta accumulated with float atomics (caller zeroes, or passes the .grad buffers to accumulate) */
 int sbl_add_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
@@ -198,6 +210,11 @@ int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, long ldk, co
                           long ldo, float* p_out, int mask_kind, const uint8_t* mask, int B, int H, const int* seg_L,
                           int nseg, int Lk_fixed, float scale, float drop_p, const uint64_t* seed, uint64_t offset,
                           sbl_stream_t stream);
+/* sbl_attention_seg_fwd for two same-shape problems (the two decoder directions) in one launch; mask_kind 0 or 1. */
+int sbl_attention_seg2_fwd(const float* q0, const float* q1, long ldq, const float* k0, const float* k1, long ldk,
+                           const float* v0, const float* v1, long ldv, float* o0, float* o1, long ldo, float* p_out0,
+                           float* p_out1, int mask_kind, int B, int H, const int* seg_L, int nseg, int Lk_fixed, float scale,
+                           float drop_p, const uint64_t* seed, uint64_t offset0, uint64_t offset1, sbl_stream_t stream);
 int sbl_attention_seg_bwd(const float* dout, long lddo, const float* q, long ldq, const float* k, long ldk, const float* v,
                           long ldv, const float* p, float* dq, long lddq, float* dk, long lddk, float* dv, long lddv,
                           int B, int H, const int* seg_L, int nseg, int Lk_fixed, float scale, float drop_p,

@@ -40,6 +40,9 @@ SIGNATURES = {
     "sbl_attention_fwd": [P, L, P, L, P, L, P, L, P, I, P, I, I, I, I, F, F, P, U64, P],
     "sbl_attention_bwd": [P, L, P, L, P, L, P, L, P, P, L, P, L, P, L, I, I, I, I, F, F, P, U64, P],
     "sbl_attention_seg_fwd": [P, L, P, L, P, L, P, L, P, I, P, I, I, P, I, I, F, F, P, U64, P],
+    "sbl_attention_seg2_fwd": [P, P, L, P, P, L, P, P, L, P, P, L, P, P, I, I, I, P, I, I, F, F, P, U64, U64, P],
+    "sbl_gemm2_f32": [I, I, I, P, P, L, P, P, L, P, P, L, P, P, I, P, L, P],
+    "sbl_add_layernorm2_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, F, P, U64, U64, P],
     "sbl_attention_seg_bwd": [P, L, P, L, P, L, P, L, P, P, L, P, L, P, L, I, I, P, I, I, F, F, P, U64, P],
     "sbl_embed_pe_seg_fwd": [P, L, P, P, P, I, P, I, I, I, P],
     "sbl_embed_seg_bwd": [P, L, P, P, I, P, I, I, I, P],

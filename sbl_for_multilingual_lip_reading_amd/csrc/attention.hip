@@ -290,12 +290,12 @@ __device__ __forceinline__ SmallProb small_prob(int prob, int B, int H, const Se
     return P;
 }
 
-__global__ __launch_bounds__(256) void attention_small_fwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ k,
-                                                                  long ldk, const float* __restrict__ v, long ldv,
-                                                                  float* __restrict__ o, long ldo, float* __restrict__ p_out,
-                                                                  int causal, int B, int H, SegDesc segs, int Lk_fixed,
-                                                                  float scale, uint32_t thresh, float keep_scale,
-                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+__device__ __forceinline__ void attention_small_fwd_body(const float* __restrict__ q, long ldq, const float* __restrict__ k,
+                                                         long ldk, const float* __restrict__ v, long ldv,
+                                                         float* __restrict__ o, long ldo, float* __restrict__ p_out,
+                                                         int causal, int B, int H, const SegDesc& segs, int Lk_fixed,
+                                                         float scale, uint32_t thresh, float keep_scale,
+                                                         const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int prob = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (prob >= nprob) return;   // whole wavefront; the kernel has no barrier
@@ -378,6 +378,32 @@ __global__ __launch_bounds__(256) void attention_small_fwd_kernel(const float* _
         const int i = 4 * g + r;
         if (i < Lq) *reinterpret_cast<float4*>(ob + (long)i * ldo + 4 * n) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
     }
+}
+__global__ __launch_bounds__(256) void attention_small_fwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ k,
+                                                                  long ldk, const float* __restrict__ v, long ldv,
+                                                                  float* __restrict__ o, long ldo, float* __restrict__ p_out,
+                                                                  int causal, int B, int H, SegDesc segs, int Lk_fixed,
+                                                                  float scale, uint32_t thresh, float keep_scale,
+                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+    attention_small_fwd_body(q, ldq, k, ldk, v, ldv, o, ldo, p_out, causal, B, H, segs, Lk_fixed, scale, thresh, keep_scale, seed, offset,
+                             nprob);
+}
+// Two same-shape problems in one launch (the two decoder directions; blockIdx.y picks the operand set).
+struct AttFwdSet {
+    const float* q;
+    const float* k;
+    const float* v;
+    float* o;
+    float* p_out;
+    uint64_t offset;
+};
+__global__ __launch_bounds__(256) void attention_small2_fwd_kernel(AttFwdSet a0, AttFwdSet a1, long ldq, long ldk, long ldv, long ldo,
+                                                                   int causal, int B, int H, SegDesc segs, int Lk_fixed, float scale,
+                                                                   uint32_t thresh, float keep_scale,
+                                                                   const uint64_t* __restrict__ seed, int nprob) {
+    const AttFwdSet& a = blockIdx.y ? a1 : a0;
+    attention_small_fwd_body(a.q, ldq, a.k, ldk, a.v, ldv, a.o, ldo, a.p_out, causal, B, H, segs, Lk_fixed, scale, thresh, keep_scale, seed,
+                             a.offset, nprob);
 }
 
 // SHARED_KV: cross-attention of a run with several segments.  All segments of one (batch, head) share the key /
@@ -634,6 +660,32 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
                        ldo, p_out, mask_kind, mask, B, H, d, Lk_fixed, scale, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
                        1.f / (1.f - drop_p), seed, offset);
     SBL_LAUNCH_CHECK("sbl_attention_fwd");
+    return 0;
+}
+
+extern "C" int sbl_attention_seg2_fwd(const float* q0, const float* q1, long ldq, const float* k0, const float* k1, long ldk,
+                                      const float* v0, const float* v1, long ldv, float* o0, float* o1, long ldo, float* p_out0,
+                                      float* p_out1, int mask_kind, int B, int H, const int* seg_L, int nseg, int Lk_fixed,
+                                      float scale, float drop_p, const uint64_t* seed, uint64_t offset0, uint64_t offset1,
+                                      sbl_stream_t stream) {
+    SegDesc d;
+    SBL_REQUIRE(sbl_make_segs(d, seg_L, nseg, B, H, Lk_fixed) > 0, "sbl_attention_seg2_fwd: bad segment list (nseg=%d, 1..%d)", nseg, SBL_MAX_SEG);
+    SBL_REQUIRE(mask_kind == 0 || mask_kind == 1, "sbl_attention_seg2_fwd: mask_kind %d (0 none, 1 causal)", mask_kind);
+    if (!at_small_ok(d, Lk_fixed, mask_kind)) {     // sizes beyond the one-wavefront kernel: two plain launches
+        if (int e = sbl_attention_seg_fwd(q0, ldq, k0, ldk, v0, ldv, o0, ldo, p_out0, mask_kind, nullptr, B, H, seg_L, nseg, Lk_fixed, scale, drop_p, seed, offset0, stream)) return e;
+        return sbl_attention_seg_fwd(q1, ldq, k1, ldk, v1, ldv, o1, ldo, p_out1, mask_kind, nullptr, B, H, seg_L, nseg, Lk_fixed, scale, drop_p, seed, offset1, stream);
+    }
+    if (int e = at_check("sbl_attention_seg2_fwd", B, H, d, Lk_fixed, ldq, ldk, ldv, ldo)) return e;
+    SBL_REQUIRE(q0 && q1 && k0 && k1 && v0 && v1 && o0 && o1 && p_out0 && p_out1, "sbl_attention_seg2_fwd: null pointer");
+    SBL_REQUIRE(sbl_aligned16(q0) && sbl_aligned16(q1) && sbl_aligned16(k0) && sbl_aligned16(k1) && sbl_aligned16(v0) && sbl_aligned16(v1) &&
+                    sbl_aligned16(o0) && sbl_aligned16(o1), "sbl_attention_seg2_fwd: unaligned pointer");
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_attention_seg2_fwd: bad dropout args");
+    const int nprob = nseg * B * H;
+    AttFwdSet a0{q0, k0, v0, o0, p_out0, offset0}, a1{q1, k1, v1, o1, p_out1, offset1};
+    hipLaunchKernelGGL(attention_small2_fwd_kernel, dim3(sbl_cdiv(nprob, 4), 2), dim3(256), 0, (hipStream_t)stream, a0, a1, ldq, ldk, ldv,
+                       ldo, mask_kind == 1, B, H, d, Lk_fixed, scale, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p),
+                       seed, nprob);
+    SBL_LAUNCH_CHECK("sbl_attention_seg2_fwd");
     return 0;
 }
 

@@ -176,6 +176,72 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
     return 0;
 }
 
+// ------------------------------------------------------------------ two same-shape products in one launch
+// C_d[M,N] = A_d[M,K] * B_d[N,K]^T (+ bias_d) (ReLU) for d = 0, 1: the nn.Linear forward of the two decoder directions
+// (SBL/transformer/decoder.py:121-156 runs layer_stack_l2r[i] and layer_stack_r2l[i] back to back on same-shape
+// inputs).  Same kernels, tiles and split rules as sbl_gemm_f32, sized for the doubled workgroup count.
+extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* A1, long lda, const float* B0, const float* B1,
+                             long ldb, float* C0, float* C1, long ldc, const float* bias0, const float* bias1, int relu,
+                             void* ws, long ws_bytes, sbl_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SBL_REQUIRE(M > 0 && N > 0 && K > 0, "sbl_gemm2_f32: non-positive dims M=%d N=%d K=%d", M, N, K);
+    SBL_REQUIRE(A0 && A1 && B0 && B1 && C0 && C1 && (!bias0 == !bias1), "sbl_gemm2_f32: null operand / one-sided bias");
+    SBL_REQUIRE(lda >= K && ldb >= K && ldc >= N, "sbl_gemm2_f32: leading dimension too small (lda=%ld ldb=%ld ldc=%ld)", lda, ldb, ldc);
+    SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_WS_COUNTERS), "sbl_gemm2_f32: workspace unaligned or < 16 KiB");
+    const bool vec = sbl_aligned16(A0) && sbl_aligned16(A1) && sbl_aligned16(B0) && sbl_aligned16(B1) && lda % 4 == 0 && ldb % 4 == 0 && K % 8 == 0;
+    const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
+    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 2048;
+    const bool big = (M >= 1024 && N >= 256 && 2 * tiles64 >= big_min);
+    if (!vec || big) {      // shapes the decoder forward does not produce: two plain launches
+        if (int e = sbl_gemm_f32(0, 1, M, N, K, A0, lda, B0, ldb, C0, ldc, bias0, relu, nullptr, 0, 0, nullptr, ws, ws_bytes, stream)) return e;
+        return sbl_gemm_f32(0, 1, M, N, K, A1, lda, B1, ldb, C1, ldc, bias1, relu, nullptr, 0, 0, nullptr, ws, ws_bytes, stream);
+    }
+    {
+        const long tiles32 = (long)sbl_cdiv(M, 32) * sbl_cdiv(N, 32);
+        // (two problems = twice the workgroups: the register-only kernel stops paying at half the rows; tools/ms.py sweep in the step)
+        static const int max_m = getenv("SBL_SKINNY_MAX_M2") ? atoi(getenv("SBL_SKINNY_MAX_M2")) : 128;
+        static const int max_t = getenv("SBL_SKINNY_MAX_TILES") ? atoi(getenv("SBL_SKINNY_MAX_TILES")) : 2048;
+        static const int sq_rows = getenv("SBL_SKINNY_SQ_ROWS2") ? atoi(getenv("SBL_SKINNY_SQ_ROWS2")) : 768;
+        if ((M <= max_m && tiles32 <= max_t) || ((long)N * K <= 512L * 512 && M <= sq_rows)) {
+            SkinnyEpi e{C0, ldc, bias0, relu, nullptr, 0, 0, nullptr, sbl_next_stamp_slot(SBL_KID_SKINNY)};
+            SkinnyDual du{A1, B1, C1, bias1};
+            sbl_launch_skinny<true, true>(A0, lda, B0, ldb, e, M, N, K, s, &du);
+            SBL_LAUNCH_CHECK("sbl_gemm2_f32(skinny)");
+            return 0;
+        }
+    }
+    int splits = 1;
+    static const int split_tiles = getenv("SBL_SPLIT_TILES") ? atoi(getenv("SBL_SPLIT_TILES")) : 192;
+    static const int split_target = getenv("SBL_SPLIT_TARGET") ? atoi(getenv("SBL_SPLIT_TARGET")) : 256;
+    if (2 * tiles64 < split_tiles && K >= 128) {
+        splits = (int)((split_target + 2 * tiles64 - 1) / (2 * tiles64));
+        if (splits > K / 64) splits = K / 64;
+        if (splits > 8) splits = 8;
+        if (splits < 1) splits = 1;
+    }
+    SplitCtl sc{nullptr, nullptr, nullptr, nullptr};
+    if (splits > 1) {
+        const long need = (long)sizeof(int) * SBL_WS_COUNTERS + 2 * tiles64 * splits * (long)(64 * 64 * sizeof(float));
+        if (ws && 2 * tiles64 < SBL_WS_COUNTERS && need <= ws_bytes) {
+            sc.counters = (int*)ws;
+            sc.slabs = (float*)((char*)ws + sizeof(int) * SBL_WS_COUNTERS);
+        } else {
+            splits = 1;
+        }
+    }
+    sc.stamp = sbl_next_stamp_slot(SBL_KID_TILED64);
+    DenseKC<64, true> al{A0, lda, M};
+    DenseKC<64, true> bl{B0, ldb, N};
+    EpiStore<0, false> e{C0, ldc, bias0, relu, nullptr, nullptr, 0};
+    GemmDual du{A1, B1, C1, bias1};
+    static const int ku_env = getenv("SBL_TILED_KU") ? atoi(getenv("SBL_TILED_KU")) : 0;
+    const int ku = ku_env ? ku_env : (2 * tiles64 * splits > 512 ? 2 : 4);
+    if (ku == 2) sbl_launch_gemm2<DenseKC<64, true>, DenseKC<64, true>, EpiStore<0, false>, 64, 64, 2>(al, bl, e, du, M, N, K, splits, s, sc);
+    else sbl_launch_gemm2<DenseKC<64, true>, DenseKC<64, true>, EpiStore<0, false>, 64, 64, 4>(al, bl, e, du, M, N, K, splits, s, sc);
+    SBL_LAUNCH_CHECK("sbl_gemm2_f32");
+    return 0;
+}
+
 // ------------------------------------------------------------------ deferred weight gradient over all decoder stages
 // C[M,N] += sum_s A_s^T B_s  (A_s: rows_s x M, B_s: rows_s x N, row-major), a_colsum[m] += column sums of A.
 // One launch per weight per step; split-K with float atomics (C is the persistent gradient buffer).

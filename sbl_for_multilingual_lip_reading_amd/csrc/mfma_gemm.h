@@ -890,6 +890,51 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
 }
 static const int g_xcd_swizzle = getenv("SBL_XCD_SWIZZLE") ? atoi(getenv("SBL_XCD_SWIZZLE")) : 1;   // A/B knob (same speed, 2.4x fewer fabric-side bytes: tools/bench_gemm7.py under --pmc FETCH_SIZE)
 
+// Two problems of one shape in one launch (the two decoder directions; see SkinnyDual): blockIdx.y in [Y, 2Y) works on
+// the second operand set.  Dense loaders and the plain-store epilogue only.
+struct GemmDual {
+    const float* A1;
+    const float* B1;
+    float* C1;
+    const float* bias1;
+};
+template <class AL, class BL, class EPI, int BM, int BN, int KU>
+__global__ __launch_bounds__(256) void sbl_mfma_gemm2_kernel(AL al, BL bl, EPI epi, SplitCtl sc, GemmDual du, int M, int N, int K,
+                                                             int kchunk) {
+    int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+    {   // XCD-aware order as in sbl_mfma_gemm_kernel, over both problems
+        const int X = gridDim.x, Y2 = gridDim.y, XY = X * Y2, T = XY * gridDim.z;
+        const int id = (z * Y2 + y) * X + x, per = T >> 3, rem = T & 7;
+        const int c = id & 7, k = id >> 3;
+        const int t = (c < rem ? c * (per + 1) : rem * (per + 1) + (c - rem) * per) + k;
+        z = t / XY;
+        const int r = t - z * XY;
+        x = r / Y2;
+        y = r - x * Y2;
+    }
+    const int tile = y * gridDim.x + x;      // unique over both problems (split-K slabs / counters)
+    const int Y = gridDim.y >> 1;
+    if (y >= Y) {
+        y -= Y;
+        al.p = du.A1;
+        bl.p = du.B1;
+        epi.C = du.C1;
+        epi.bias = du.bias1;
+    }
+    const int kbeg = z * kchunk;
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, 2>(al, bl, epi, sc, M, N, x * BM, y * BN, kbeg, min(K, kbeg + kchunk), tile, z,
+                                              gridDim.z, false);
+}
+template <class AL, class BL, class EPI, int BM, int BN, int KU>
+static inline void sbl_launch_gemm2(const AL& al, const BL& bl, const EPI& epi, const GemmDual& du, int M, int N, int K, int splits,
+                                    hipStream_t s, SplitCtl sc) {
+    constexpr int MK = KU * SBL_BK;
+    int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
+    int nz = sbl_cdiv(K, kchunk);
+    dim3 grid(sbl_cdiv(M, BM), 2 * sbl_cdiv(N, BN), nz);
+    hipLaunchKernelGGL((sbl_mfma_gemm2_kernel<AL, BL, EPI, BM, BN, KU>), grid, dim3(256), 0, s, al, bl, epi, sc, du, M, N, K, kchunk);
+}
+
 // Position-major convolution tiles (ConvGatherPM x DenseKCTapList): the workgroup's tap list = union of the in-bounds
 // taps of the (at most two, when NIMG >= BM) positions its rows cover.
 template <bool DGRAD>

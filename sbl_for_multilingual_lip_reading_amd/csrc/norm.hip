@@ -292,12 +292,12 @@ extern "C" int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream) {
 // ------------------------------------------------------------------ residual + LayerNorm (D = 512)
 // One wavefront per row: 8 floats per lane (two float4), mean / variance by wave shuffles.
 // attention.py:57-58, module.py:50-51, encoder.py:53-54 (torch LayerNorm: biased variance, eps inside sqrt)
-__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ y, float* __restrict__ mean,
-                                                                float* __restrict__ rstd, int M, float eps, uint32_t thresh,
-                                                                float keep_scale, const uint64_t* __restrict__ seed,
-                                                                uint64_t offset) {
+__device__ __forceinline__ void add_layernorm_fwd_rows(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int M, float eps, uint32_t thresh,
+                                                       float keep_scale, const uint64_t* __restrict__ seed,
+                                                       uint64_t offset) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -340,6 +340,31 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
         mean[row] = mu;
         rstd[row] = rs;
     }
+}
+
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ y, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int M, float eps, uint32_t thresh,
+                                                                float keep_scale, const uint64_t* __restrict__ seed,
+                                                                uint64_t offset) {
+    add_layernorm_fwd_rows(x, res, gamma, beta, y, mean, rstd, M, eps, thresh, keep_scale, seed, offset);
+}
+// Two same-shape problems in one launch (the two decoder directions; blockIdx.y picks the operand set).
+struct LnFwdSet {
+    const float* x;
+    const float* res;
+    const float* gamma;
+    const float* beta;
+    float* y;
+    float* mean;
+    float* rstd;
+    uint64_t offset;
+};
+__global__ __launch_bounds__(256) void add_layernorm2_fwd_kernel(LnFwdSet a0, LnFwdSet a1, int M, float eps, uint32_t thresh,
+                                                                 float keep_scale, const uint64_t* __restrict__ seed) {
+    const LnFwdSet& a = blockIdx.y ? a1 : a0;
+    add_layernorm_fwd_rows(a.x, a.res, a.gamma, a.beta, a.y, a.mean, a.rstd, M, eps, thresh, keep_scale, seed, a.offset);
 }
 
 // dz = rstd*(gamma*dy - mean(gamma*dy) - xhat*mean(gamma*dy*xhat)); dgamma += dy*xhat, dbeta += dy (column sums:
@@ -444,6 +469,23 @@ extern "C" int sbl_add_layernorm_fwd(const float* x, const float* res, const flo
                        beta, y, mean, rstd, M, eps, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed,
                        offset);
     SBL_LAUNCH_CHECK("sbl_add_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int sbl_add_layernorm2_fwd(const float* x0, const float* x1, const float* res0, const float* res1, const float* gamma0,
+                                      const float* gamma1, const float* beta0, const float* beta1, float* y0, float* y1,
+                                      float* mean0, float* mean1, float* rstd0, float* rstd1, int M, int D, float eps, float drop_p,
+                                      const uint64_t* seed, uint64_t offset0, uint64_t offset1, sbl_stream_t stream) {
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_add_layernorm2_fwd: bad dropout args");
+    SBL_REQUIRE(D == 512, "sbl_add_layernorm2_fwd: D=%d (this build is specialised for d_model=512)", D);
+    SBL_REQUIRE(x0 && x1 && gamma0 && gamma1 && beta0 && beta1 && y0 && y1 && mean0 && mean1 && rstd0 && rstd1 && M > 0 && (!res0 == !res1),
+                "sbl_add_layernorm2_fwd: bad args");
+    SBL_REQUIRE(sbl_aligned16(x0) && sbl_aligned16(x1) && sbl_aligned16(y0) && sbl_aligned16(y1) && (!res0 || (sbl_aligned16(res0) && sbl_aligned16(res1))) &&
+                    sbl_aligned16(gamma0) && sbl_aligned16(gamma1) && sbl_aligned16(beta0) && sbl_aligned16(beta1), "sbl_add_layernorm2_fwd: unaligned");
+    LnFwdSet a0{x0, res0, gamma0, beta0, y0, mean0, rstd0, offset0}, a1{x1, res1, gamma1, beta1, y1, mean1, rstd1, offset1};
+    hipLaunchKernelGGL(add_layernorm2_fwd_kernel, dim3(sbl_cdiv(M, 4), 2), dim3(256), 0, (hipStream_t)stream, a0, a1, M, eps,
+                       drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed);
+    SBL_LAUNCH_CHECK("sbl_add_layernorm2_fwd");
     return 0;
 }
 

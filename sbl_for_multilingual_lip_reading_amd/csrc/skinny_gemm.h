@@ -48,11 +48,28 @@ struct SkinnyEpi {
     unsigned long long* stamp;   // bench instrumentation slot or nullptr
 };
 
+// Second problem of the same shape (the other decoder direction: its own operands, output and bias), handled by the
+// workgroups with blockIdx.z == 1 of the same launch; all nullptr / gridDim.z == 1 otherwise.  Kernel boundaries
+// cost ~5 us each and launches on two streams do not overlap at these sizes (tools/bench_twochain.py), so the two
+// directions of the decoder forward share launches instead of streams.
+struct SkinnyDual {
+    const float* A1;
+    const float* B1;
+    float* C1;
+    const float* bias1;
+};
+
 template <bool AKC, bool BKC, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void sbl_skinny_gemm_kernel(SkinnyOperand<AKC> a, SkinnyOperand<BKC> b, SkinnyEpi e,
-                                                                  int M, int N, int K) {
+                                                                  SkinnyDual du, int M, int N, int K) {
     __shared__ float red[NW][1024];
     __shared__ float csum[NW][32];
+    if (blockIdx.z) {
+        a.p = du.A1;
+        b.p = du.B1;
+        e.C = du.C1;
+        e.bias = du.bias1;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i31 = lane & 31, h = lane >> 5;
     // XCD-aware tile order (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each
@@ -147,11 +164,12 @@ __global__ __launch_bounds__(NW * 64) void sbl_skinny_gemm_kernel(SkinnyOperand<
 
 template <bool AKC, bool BKC>
 static inline void sbl_launch_skinny(const float* A, long lda, const float* B, long ldb, const SkinnyEpi& e, int M, int N,
-                                     int K, hipStream_t s) {
+                                     int K, hipStream_t s, const SkinnyDual* dual = nullptr) {
     SkinnyOperand<AKC> a{A, lda, M};
     SkinnyOperand<BKC> b{B, ldb, N};
-    dim3 grid(sbl_cdiv(M, 32), sbl_cdiv(N, 32));
-    if (K >= 1024) hipLaunchKernelGGL((sbl_skinny_gemm_kernel<AKC, BKC, 8, 8>), grid, dim3(512), 0, s, a, b, e, M, N, K);
-    else if (K >= 512) hipLaunchKernelGGL((sbl_skinny_gemm_kernel<AKC, BKC, 8, 4>), grid, dim3(512), 0, s, a, b, e, M, N, K);
-    else hipLaunchKernelGGL((sbl_skinny_gemm_kernel<AKC, BKC, 4, 4>), grid, dim3(256), 0, s, a, b, e, M, N, K);
+    const SkinnyDual du = dual ? *dual : SkinnyDual{nullptr, nullptr, nullptr, nullptr};
+    dim3 grid(sbl_cdiv(M, 32), sbl_cdiv(N, 32), dual ? 2 : 1);
+    if (K >= 1024) hipLaunchKernelGGL((sbl_skinny_gemm_kernel<AKC, BKC, 8, 8>), grid, dim3(512), 0, s, a, b, e, du, M, N, K);
+    else if (K >= 512) hipLaunchKernelGGL((sbl_skinny_gemm_kernel<AKC, BKC, 8, 4>), grid, dim3(512), 0, s, a, b, e, du, M, N, K);
+    else hipLaunchKernelGGL((sbl_skinny_gemm_kernel<AKC, BKC, 4, 4>), grid, dim3(256), 0, s, a, b, e, du, M, N, K);
 }

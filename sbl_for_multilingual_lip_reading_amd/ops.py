@@ -347,6 +347,13 @@ def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, relu=0, mask=None, 
          accumulate, _p(colsum), ws.data_ptr(), WS_BYTES, _s())
 
 
+def gemm2(M, N, K, A0, A1, lda, B0, B1, ldb, C0, C1, ldc, bias0=None, bias1=None, relu=0):
+    """C_d = A_d @ B_d^T (+ bias_d) (ReLU) for two same-shape problems in one launch (the two decoder directions)."""
+    ws = _workspace()
+    call("sbl_gemm2_f32", M, N, K, _p(A0), _p(A1), lda, _p(B0), _p(B1), ldb, _p(C0), _p(C1), ldc, _p(bias0), _p(bias1), relu,
+         ws.data_ptr(), WS_BYTES, _s())
+
+
 import ctypes as _ct
 
 _seg_arrays = {}

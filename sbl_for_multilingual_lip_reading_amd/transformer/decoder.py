@@ -76,6 +76,7 @@ class Decoder(nn.Module):
         self.tgt_word_prj_r2l = nn.Linear(512, 58, bias=False)
 
         self.batched_backward = True     # one stage-batched backward over all 16 steps (decoder_stages.py) when possible
+        self.merge_directions = True     # ... whose forward runs both directions in shared launches (sbl_*2_* entry points)
         self.two_streams = True          # run the two directions' layers on two HIP streams (joined before each fusion)
         self.batch_teacher_runs = True   # batch the steps of a teacher-forced run (see class docstring)
         self.coins_dev = None            # optional device int32[16]: 1 = feed own argmax (graph replay, per-step schedule)

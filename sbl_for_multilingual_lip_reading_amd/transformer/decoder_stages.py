@@ -182,6 +182,50 @@ class DecoderStagesFn(torch.autograd.Function):
             call("sbl_add_layernorm_fwd", _p(b["o_f"][r0:r1]), _p(y_e), _p(g), _p(be), _p(b["y_f"][r0:r1]), _p(b["mu_f"][r0:r1]),
                  _p(b["rs_f"][r0:r1]), M, D, eps, L.drop_f, _p(seed) if L.drop_f > 0 else None, _fold(b["off"][4], r0 * D), ops._s())
 
+        def layer_fwd2(n, r0, r1, i0, segL):
+            """Both directions of layer n in shared launches (same shapes, their own operands): kernel boundaries cost
+            ~5 us each and small launches on two streams do not overlap, so the directions share launches, not streams."""
+            L0, L1, b0, b1 = layers[0][n], layers[1][n], B_[0][n], B_[1][n]
+            M = r1 - r0
+            seg_arr, nseg = segs(segL)
+            sl = lambda b, k: b[k][r0:r1]
+            sp = _p(seed) if training else None
+            # self-attention sub-layer
+            q0, q1 = sl(b0, "qkv"), sl(b1, "qkv")
+            ops.gemm2(M, 3 * HD, D, sl(b0, "x"), sl(b1, "x"), D, L0.wqkv, L1.wqkv, D, q0, q1, 3 * HD, L0.bqkv, L1.bqkv)
+            call("sbl_attention_seg2_fwd", _p(q0), _p(q1), 3 * HD, _p(q0[:, HD:]), _p(q1[:, HD:]), 3 * HD, _p(q0[:, 2 * HD:]), _p(q1[:, 2 * HD:]),
+                 3 * HD, _p(sl(b0, "att")), _p(sl(b1, "att")), HD, b0["ps"].data_ptr() + 4 * ps_off[i0], b1["ps"].data_ptr() + 4 * ps_off[i0],
+                 1 if n == 0 else 0, N, H, seg_arr, nseg, 0, 0.125, L0.drop_s, sp if L0.drop_s > 0 else None,
+                 _fold(b0["off"][0], ps_off[i0]), _fold(b1["off"][0], ps_off[i0]), ops._s())
+            ops.gemm2(M, D, HD, sl(b0, "att"), sl(b1, "att"), HD, L0.wfc_s, L1.wfc_s, HD, sl(b0, "o_s"), sl(b1, "o_s"), D, L0.bfc_s, L1.bfc_s)
+
+            def ln2(o, res, y, mu, rs, ln0, ln1, drop_p, k):
+                call("sbl_add_layernorm2_fwd", _p(sl(b0, o)), _p(sl(b1, o)), _p(sl(b0, res)), _p(sl(b1, res)), _p(ln0[0]), _p(ln1[0]),
+                     _p(ln0[1]), _p(ln1[1]), _p(sl(b0, y)), _p(sl(b1, y)), _p(sl(b0, mu)), _p(sl(b1, mu)), _p(sl(b0, rs)), _p(sl(b1, rs)),
+                     M, D, ln0[4], drop_p, sp if drop_p > 0 else None, _fold(b0["off"][k], r0 * D), _fold(b1["off"][k], r0 * D), ops._s())
+
+            ln2("o_s", "x", "y_s", "mu_s", "rs_s", L0.ln_s, L1.ln_s, L0.drop_s, 1)
+            # cross-attention sub-layer
+            ops.gemm2(M, HD, D, sl(b0, "y_s"), sl(b1, "y_s"), D, L0.wq, L1.wq, D, sl(b0, "q"), sl(b1, "q"), HD, L0.bq, L1.bq)
+            kv0, kv1 = b0["kv"], b1["kv"]
+            call("sbl_attention_seg2_fwd", _p(sl(b0, "q")), _p(sl(b1, "q")), HD, _p(kv0), _p(kv1), 2 * HD, _p(kv0[:, HD:]), _p(kv1[:, HD:]), 2 * HD,
+                 _p(sl(b0, "att2")), _p(sl(b1, "att2")), HD, b0["pe"].data_ptr() + 4 * pe_off[i0], b1["pe"].data_ptr() + 4 * pe_off[i0],
+                 0, N, H, seg_arr, nseg, T, 0.125, L0.drop_e, sp if L0.drop_e > 0 else None,
+                 _fold(b0["off"][2], pe_off[i0]), _fold(b1["off"][2], pe_off[i0]), ops._s())
+            ops.gemm2(M, D, HD, sl(b0, "att2"), sl(b1, "att2"), HD, L0.wfc_e, L1.wfc_e, HD, sl(b0, "o_e"), sl(b1, "o_e"), D, L0.bfc_e, L1.bfc_e)
+            ln2("o_e", "y_s", "y_e", "mu_e", "rs_e", L0.ln_e, L1.ln_e, L0.drop_e, 3)
+            # position-wise feed-forward sub-layer
+            ops.gemm2(M, F_, D, sl(b0, "y_e"), sl(b1, "y_e"), D, L0.w1, L1.w1, D, sl(b0, "h"), sl(b1, "h"), F_, L0.b1, L1.b1, relu=1)
+            ops.gemm2(M, D, F_, sl(b0, "h"), sl(b1, "h"), F_, L0.w2, L1.w2, F_, sl(b0, "o_f"), sl(b1, "o_f"), D, L0.b2, L1.b2)
+            ln2("o_f", "y_e", "y_f", "mu_f", "rs_f", L0.ln_f, L1.ln_f, L0.drop_f, 4)
+
+        merged = getattr(dec, "merge_directions", True) and all(
+            (layers[0][n].drop_s, layers[0][n].drop_e, layers[0][n].drop_f, layers[0][n].ln_s[4], layers[0][n].ln_e[4], layers[0][n].ln_f[4]) ==
+            (layers[1][n].drop_s, layers[1][n].drop_e, layers[1][n].drop_f, layers[1][n].ln_s[4], layers[1][n].ln_e[4], layers[1][n].ln_f[4])
+            for n in range(nl))
+        if merged and side is not None:
+            main.wait_stream(side)       # the r2l K/V projections above ran on the side stream
+
         for (i0, i1) in stages:
             segL = tuple(range(i0 + 1, i1 + 2))
             seg_arr, nseg = segs(segL)
@@ -193,13 +237,16 @@ class DecoderStagesFn(torch.autograd.Function):
                 if p_emb > 0:
                     call("sbl_dropout", _p(dst), _p(B_[d][0]["x"][r0:r1]), M * D, p_emb, _p(seed), _fold(off_emb[d], r0 * D), ops._s())
             for n in range(nl):
-                if side is not None:
-                    side.wait_stream(main)
-                for d in (0, 1):
-                    with torch.cuda.stream(streams[d]):
-                        layer_fwd(d, n, r0, r1, i0, segL)
-                if side is not None:
-                    main.wait_stream(side)
+                if merged:
+                    layer_fwd2(n, r0, r1, i0, segL)
+                else:
+                    if side is not None:
+                        side.wait_stream(main)
+                    for d in (0, 1):
+                        with torch.cuda.stream(streams[d]):
+                            layer_fwd(d, n, r0, r1, i0, segL)
+                    if side is not None:
+                        main.wait_stream(side)
                 nxt = [B_[d][n + 1]["x"][r0:r1] if n + 1 < nl else xout[d][r0:r1] for d in (0, 1)]
                 call("sbl_fusion_seg_fwd", _p(B_[0][n]["y_f"][r0:r1]), _p(B_[1][n]["y_f"][r0:r1]), _p(nxt[0]), _p(nxt[1]), N, seg_arr, nseg,
                      D, ops._s())

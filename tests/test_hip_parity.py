@@ -85,6 +85,74 @@ def test_gemm_epilogues_and_strides(ops):
     assert maxdiff(cs, (2 * ref).sum(0)) < 1e-3
 
 
+# --------------------------------------------------------------------------- two problems per launch (decoder directions)
+@pytest.mark.parametrize("M,N,K,relu", [(32, 512, 512, 0), (96, 1536, 512, 0), (416, 2048, 512, 1), (640, 512, 2048, 0),
+                                        (992, 512, 512, 0), (1440, 1536, 512, 0), (2208, 2048, 512, 1), (2208, 512, 2048, 0),
+                                        (70, 58, 512, 0)])
+def test_gemm2_equals_two_products(ops, M, N, K, relu):
+    A = [U("g2a%d%d%d" % (M, K, d), (M, K)).to(DEV) for d in (0, 1)]
+    B = [U("g2b%d%d%d" % (N, K, d), (N, K), 0.05).to(DEV) for d in (0, 1)]
+    bias = [U("g2c%d%d" % (N, d), (N,)).to(DEV) for d in (0, 1)]
+    C = [torch.full((M, N), float("nan"), device=DEV) for _ in (0, 1)]
+    ops.gemm2(M, N, K, A[0], A[1], K, B[0], B[1], K, C[0], C[1], N, bias[0], bias[1], relu=relu)
+    assert float(ops._workspace()[:4096].abs().max()) == 0.0      # split-K tile counters re-armed
+    for d in (0, 1):
+        ref = A[d].double() @ B[d].double().t() + bias[d].double()
+        if relu:
+            ref = ref.clamp_min(0)
+        assert maxdiff(C[d], ref) < 4e-7 * K ** 0.5 * 4
+
+
+def test_layernorm2_and_attention2_equal_single_launches(ops):
+    M, D, N, H = 416, 512, 32, 8
+    seed = torch.tensor([1234567], dtype=torch.int64, device=DEV)
+    x = [U("l2x%d" % d, (M, D)).to(DEV) for d in (0, 1)]
+    r = [U("l2r%d" % d, (M, D)).to(DEV) for d in (0, 1)]
+    g = [U("l2g%d" % d, (D,)).to(DEV) for d in (0, 1)]
+    b = [U("l2b%d" % d, (D,)).to(DEV) for d in (0, 1)]
+    outs = {}
+    for mode in ("single", "dual"):
+        y = [torch.empty(M, D, device=DEV) for _ in (0, 1)]
+        mu = [torch.empty(M, device=DEV) for _ in (0, 1)]
+        rs = [torch.empty(M, device=DEV) for _ in (0, 1)]
+        if mode == "single":
+            for d in (0, 1):
+                ops.call("sbl_add_layernorm_fwd", x[d].data_ptr(), r[d].data_ptr(), g[d].data_ptr(), b[d].data_ptr(), y[d].data_ptr(),
+                         mu[d].data_ptr(), rs[d].data_ptr(), M, D, 1e-5, 0.1, seed.data_ptr(), 11 + d, ops._s())
+        else:
+            ops.call("sbl_add_layernorm2_fwd", x[0].data_ptr(), x[1].data_ptr(), r[0].data_ptr(), r[1].data_ptr(), g[0].data_ptr(),
+                     g[1].data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y[0].data_ptr(), y[1].data_ptr(), mu[0].data_ptr(), mu[1].data_ptr(),
+                     rs[0].data_ptr(), rs[1].data_ptr(), M, D, 1e-5, 0.1, seed.data_ptr(), 11, 12, ops._s())
+        outs[mode] = y + mu + rs
+    for a, c in zip(outs["single"], outs["dual"]):
+        assert torch.equal(a, c)
+    # ragged self-attention (causal) and cross-attention over the same keys, both directions
+    segL = (6, 7)
+    seg_arr, nseg = ops._segs(segL)
+    rows, T = N * sum(segL), 29
+    for Lk_fixed, causal in ((0, 1), (T, 0)):
+        q = [U("a2q%d%d" % (d, Lk_fixed), (rows, H * 64)).to(DEV) for d in (0, 1)]
+        krows = rows if Lk_fixed == 0 else N * T
+        k = [U("a2k%d%d" % (d, Lk_fixed), (krows, H * 64)).to(DEV) for d in (0, 1)]
+        v = [U("a2v%d%d" % (d, Lk_fixed), (krows, H * 64)).to(DEV) for d in (0, 1)]
+        psz = H * N * sum(L * (L if Lk_fixed == 0 else T) for L in segL)
+        res = {}
+        for mode in ("single", "dual"):
+            o = [torch.empty(rows, H * 64, device=DEV) for _ in (0, 1)]
+            pr = [torch.empty(psz, device=DEV) for _ in (0, 1)]
+            if mode == "single":
+                for d in (0, 1):
+                    ops.call("sbl_attention_seg_fwd", q[d].data_ptr(), H * 64, k[d].data_ptr(), H * 64, v[d].data_ptr(), H * 64, o[d].data_ptr(),
+                             H * 64, pr[d].data_ptr(), causal, None, N, H, seg_arr, nseg, Lk_fixed, 0.125, 0.1, seed.data_ptr(), 21 + d, ops._s())
+            else:
+                ops.call("sbl_attention_seg2_fwd", q[0].data_ptr(), q[1].data_ptr(), H * 64, k[0].data_ptr(), k[1].data_ptr(), H * 64,
+                         v[0].data_ptr(), v[1].data_ptr(), H * 64, o[0].data_ptr(), o[1].data_ptr(), H * 64, pr[0].data_ptr(), pr[1].data_ptr(),
+                         causal, N, H, seg_arr, nseg, Lk_fixed, 0.125, 0.1, seed.data_ptr(), 21, 22, ops._s())
+            res[mode] = o + pr
+        for a, c in zip(res["single"], res["dual"]):
+            assert torch.equal(a, c)
+
+
 # --------------------------------------------------------------------------- trunk convolutions
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
