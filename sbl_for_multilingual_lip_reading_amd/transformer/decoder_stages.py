@@ -126,14 +126,24 @@ class DecoderStagesFn(torch.autograd.Function):
             y[:, 0] = dec.sos_id
         seed = st.seed
 
-        # ---- hoisted cross-attention K/V, one GEMM per layer and direction (r2l on the side stream)
-        if side is not None:
-            side.wait_stream(main)
-        for d in (0, 1):
-            with torch.cuda.stream(streams[d]):
-                for n in range(nl):
-                    L = layers[d][n]
-                    gemm(0, 1, N * T, 2 * HD, D, enc2, D, L.wkv, D, B_[d][n]["kv"], 2 * HD, bias=L.bkv)
+        # ---- hoisted cross-attention K/V: one launch per layer for both directions, or one GEMM per layer and direction
+        # with r2l on the side stream
+        merged = getattr(dec, "merge_directions", True) and all(
+            (layers[0][n].drop_s, layers[0][n].drop_e, layers[0][n].drop_f, layers[0][n].ln_s[4], layers[0][n].ln_e[4], layers[0][n].ln_f[4]) ==
+            (layers[1][n].drop_s, layers[1][n].drop_e, layers[1][n].drop_f, layers[1][n].ln_s[4], layers[1][n].ln_e[4], layers[1][n].ln_f[4])
+            for n in range(nl))
+        if merged:
+            for n in range(nl):
+                L0, L1 = layers[0][n], layers[1][n]
+                ops.gemm2(N * T, 2 * HD, D, enc2, enc2, D, L0.wkv, L1.wkv, D, B_[0][n]["kv"], B_[1][n]["kv"], 2 * HD, L0.bkv, L1.bkv)
+        else:
+            if side is not None:
+                side.wait_stream(main)
+            for d in (0, 1):
+                with torch.cuda.stream(streams[d]):
+                    for n in range(nl):
+                        L = layers[d][n]
+                        gemm(0, 1, N * T, 2 * HD, D, enc2, D, L.wkv, D, B_[d][n]["kv"], 2 * HD, bias=L.bkv)
 
         # ---- stages (same rule as Decoder._run)
         stages, i = [], 0
@@ -218,13 +228,6 @@ class DecoderStagesFn(torch.autograd.Function):
             ops.gemm2(M, F_, D, sl(b0, "y_e"), sl(b1, "y_e"), D, L0.w1, L1.w1, D, sl(b0, "h"), sl(b1, "h"), F_, L0.b1, L1.b1, relu=1)
             ops.gemm2(M, D, F_, sl(b0, "h"), sl(b1, "h"), F_, L0.w2, L1.w2, F_, sl(b0, "o_f"), sl(b1, "o_f"), D, L0.b2, L1.b2)
             ln2("o_f", "y_e", "y_f", "mu_f", "rs_f", L0.ln_f, L1.ln_f, L0.drop_f, 4)
-
-        merged = getattr(dec, "merge_directions", True) and all(
-            (layers[0][n].drop_s, layers[0][n].drop_e, layers[0][n].drop_f, layers[0][n].ln_s[4], layers[0][n].ln_e[4], layers[0][n].ln_f[4]) ==
-            (layers[1][n].drop_s, layers[1][n].drop_e, layers[1][n].drop_f, layers[1][n].ln_s[4], layers[1][n].ln_e[4], layers[1][n].ln_f[4])
-            for n in range(nl))
-        if merged and side is not None:
-            main.wait_stream(side)       # the r2l K/V projections above ran on the side stream
 
         for (i0, i1) in stages:
             segL = tuple(range(i0 + 1, i1 + 2))
