@@ -40,7 +40,7 @@ T_FRAMES, HW = 29, 88
 PER_GPU_BATCH = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW, M<=512)",
-                2: "sbl_mfma_gemm_kernel 64x64 dense (nn.Linear, M>512)",
+                2: "sbl_mfma_gemm_kernel / sbl_mfma_gemm2_kernel 64x64 dense (nn.Linear, M>512; gemm2 = both decoder directions per launch)",
                 3: "sbl_mfma_gemm_kernel 128x128 dense",
                 4: "sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (trunk conv fwd + BN stats)",
                 5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
@@ -52,7 +52,7 @@ KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm_kernel<Dense[K
                  4: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, false>",
                  5: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, true>",
                  6: r"(sbl_mfma_gemm_kernel<DenseMC<\d+, true>, ConvGatherMC|sbl_conv_pm_wgrad_kernel)", 7: r"sbl_wgrad_group_kernel"}
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_i_pmc_fetch_write_per_kernel.csv")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_j_pmc_fetch_write_per_kernel.csv")
 T_START = time.perf_counter()
 
 
