@@ -15,9 +15,13 @@ static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout
 }
 static inline int out_dim(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
 
-// Position-major path for 3x3 / stride-1 convolutions on small maps (ResNet layers 3, 4): SBL_CONV_PM_HW = largest
-// Ho*Wo that takes it (0 = off; A/B knob)
-static const int g_pm_hw = getenv("SBL_CONV_PM_HW") ? atoi(getenv("SBL_CONV_PM_HW")) : 36;
+// Position-major path for 3x3 / stride-1 convolutions on small maps (ResNet layers 2-4: 11x11, 6x6, 3x3): SBL_CONV_PM_HW =
+// largest Ho*Wo that takes it (0 = off; A/B knob; the 22x22 maps of layer 1 lose: 6 % padding, 434 vs 396 us)
+static const int g_pm_hw = getenv("SBL_CONV_PM_HW") ? atoi(getenv("SBL_CONV_PM_HW")) : 121;
+// forward / input-gradient tile of that path: 1 = 128x128, 2 = 128x64, 3 = 64x64, 0 = the ordinary launches' rule.  The
+// tiles are uneven (4 / 6 / 9 taps) and co-resident, so small tiles balance best: layer 4 forward 400 -> 307 us
+// (128 TF of algorithmic FLOPs), input gradient 431 -> 324 us; layer 2 352 -> 327 us
+static const int g_pm_tile = getenv("SBL_CONV_PM_TILE") ? atoi(getenv("SBL_CONV_PM_TILE")) : 3;
 static inline bool conv_pm_ok(int Ho, int Wo, int KH, int stride) { return KH == 3 && stride == 1 && Ho * Wo <= g_pm_hw; }
 
 #define SBL_CONV_WS_COUNTERS 4096      // same workspace convention as sbl_gemm_f32: int counters, then fp32 slabs
@@ -68,8 +72,8 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
             hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, false>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, false>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
         }                                                                                                      \
     } while (0)
-        if (N >= 128 && t128 >= 512) SBL_CONV_FWD_PM(128, 128);
-        else if ((long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_FWD_PM(128, 64);
+        if (g_pm_tile == 1 || (!g_pm_tile && N >= 128 && t128 >= 512)) SBL_CONV_FWD_PM(128, 128);
+        else if (g_pm_tile == 2 || (!g_pm_tile && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512)) SBL_CONV_FWD_PM(128, 64);
         else SBL_CONV_FWD_PM(64, 64);
 #undef SBL_CONV_FWD_PM
         SBL_LAUNCH_CHECK("sbl_conv2d_fwd(pm)");
@@ -145,8 +149,8 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
         EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};        \
         hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
     } while (0)
-        if (N >= 128 && t128 >= 512) SBL_CONV_DG_PM(128, 128);
-        else if ((long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG_PM(128, 64);
+        if (g_pm_tile == 1 || (!g_pm_tile && N >= 128 && t128 >= 512)) SBL_CONV_DG_PM(128, 128);
+        else if (g_pm_tile == 2 || (!g_pm_tile && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512)) SBL_CONV_DG_PM(128, 64);
         else SBL_CONV_DG_PM(64, 64);
 #undef SBL_CONV_DG_PM
         SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(pm)");
