@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="clips per GPU")
     ap.add_argument("--workload", default="full", choices=["full", "frontend"])
     ap.add_argument("--no-graph", action="store_true", help="run eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--mode", choices=("auto", "graph", "eager"), default="auto",
+                    help="how the step is issued: replayed hipGraphs, eager launches, or (auto) whichever a short trial of both "
+                         "finds faster on this box (same on every rank)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the instrumented replays behind `roofline`")
@@ -302,7 +305,7 @@ def main():
     torch.cuda.synchronize()
     log(args, "eager warm-up done")
 
-    use_split = args.workload == "full" and not args.no_graph and (args.split_graph == "on" or (args.split_graph == "auto" and world > 1))
+    use_split = args.workload == "full" and not args.no_graph and args.mode != "eager" and (args.split_graph == "on" or (args.split_graph == "auto" and world > 1))
     graph = None
     graphs = []
     # With a process group alive other threads (collective watchdog) may touch the runtime while this thread captures:
@@ -317,7 +320,7 @@ def main():
             fn()
         return g
 
-    if not args.no_graph:
+    if not args.no_graph and args.mode != "eager":
         try:
             for i in range(len(patterns)):
                 set_coins(i)
@@ -347,28 +350,68 @@ def main():
             print("[bench] graph capture failed (%s: %s); running the eager step" % (type(e).__name__, e), file=sys.stderr, flush=True)
             split.clear()
             graph, graphs, use_split = None, [], False
-            exchange = dp.GradientExchange(flat, world, overlap=True)
         torch.cuda.synchronize()
     step_no = [0]
 
-    def step():
+    def step_graph():
         i = step_no[0]
         step_no[0] += 1
-        if graph is not None and use_split:
+        if use_split:
             ga, gb = graphs[i % len(graphs)]
             ga.replay()
             exchange.launch("decoder.")      # side stream: runs beside the frontend backward below
             exchange.launch("encoder.")
             gb.replay()
             exchange.finish()                # frontend segment + join
-        elif graph is not None:
+        else:
             graphs[i % len(graphs)].replay()
             exchange.finish()
-        else:
-            set_coins(i)
-            with torch.cuda.stream(cap_stream):
-                fwd_bwd()
-                exchange.finish()
+
+    eager_exchange = [None]
+
+    def step_eager():
+        i = step_no[0]
+        step_no[0] += 1
+        if eager_exchange[0] is None:        # decoder / encoder segments are all-reduced from hooks inside backward
+            eager_exchange[0] = dp.GradientExchange(flat, world, overlap=True)
+        set_coins(i)
+        with torch.cuda.stream(cap_stream):
+            fwd_bwd()
+            eager_exchange[0].finish()
+
+    def trial(fn, n):
+        """ms per step over n steps, max over ranks (every rank must reach the same decision)"""
+        step_no[0] = 0
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t) / n * 1e3], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    mode = "eager" if (args.no_graph or graph is None) else args.mode
+    trial_ms = {}
+    if mode == "auto":
+        n_trial = 2 * len(patterns)
+        trial_ms["graph"] = trial(step_graph, n_trial)
+        trial_ms["eager"] = trial(step_eager, n_trial)
+        mode = "graph" if trial_ms["graph"] <= trial_ms["eager"] else "eager"
+        log(args, "trial: graph %.2f ms, eager %.2f ms -> %s" % (trial_ms["graph"], trial_ms["eager"], mode))
+    if mode == "eager":
+        graph, use_split = None, False
+        if eager_exchange[0] is None:
+            eager_exchange[0] = dp.GradientExchange(flat, world, overlap=True)
+        exchange = eager_exchange[0]
+    elif eager_exchange[0] is not None:
+        eager_exchange[0].close()            # no collectives from hooks while graphs replay
+    step = step_graph if mode == "graph" else step_eager
+    step_no[0] = 0
 
     step()
     torch.cuda.synchronize()
@@ -455,7 +498,7 @@ def main():
             "config": {"workload": ("full SBL 6+6 (Conv3d stem + ResNet-18 + encoder + SBL decoder) fwd+loss+bwd"
                                     if args.workload == "full" else "visual frontend only (Conv3d stem + ResNet-18) fwd+bwd"),
                        "per_gpu_batch": B, "global_batch": B * world, "clip": "29x88x88", "parallelism": "dp%d" % world,
-                       "dropout": not args.no_dropout, "bn": "train", "hipgraph": graph is not None, "graphs_per_step": 2 if (graph is not None and use_split) else 1,
+                       "dropout": not args.no_dropout, "bn": "train", "issue": mode, "trial_ms": trial_ms or None, "hipgraph": graph is not None, "graphs_per_step": 2 if (graph is not None and use_split) else 1,
                        "decoder_streams": 1 if args.single_stream else 2,
                        "decoder_schedule": "per-step" if args.per_step_decoder else "teacher-forced runs batched",
                        "coin_patterns": len(patterns), "own_argmax_coins": [sum(p_) for p_ in patterns],

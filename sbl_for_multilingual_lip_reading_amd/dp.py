@@ -144,6 +144,12 @@ class GradientExchange:
         self._hooks.append(model.encoder.register_forward_hook(on_encoder_out))
         self._hooks.append(model.visual_frontend.register_forward_hook(on_frontend_out))
 
+    def close(self):
+        """Remove the forward hooks (the exchange then only runs when launch() / finish() are called explicitly)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
     def launch(self, seg):
         if self.world <= 1:
             return
