@@ -389,6 +389,7 @@ def main():
         t = time.perf_counter()
         for _ in range(n):
             fn()
+        log(args, "  host side of %s: %.2f ms/step to issue" % (fn.__name__, (time.perf_counter() - t) / n * 1e3))
         torch.cuda.synchronize()
         t = torch.tensor([(time.perf_counter() - t) / n * 1e3], device=dev, dtype=torch.float64)
         if world > 1:

@@ -147,6 +147,14 @@ int sbl_conv2d_fwd(const float* x, const float* w_ohwi, float* y, double* stats,
                    int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream);
 int sbl_conv2d_dgrad(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream);
+/* The same, and in its epilogue the reduction pass of the BatchNorm backward that consumes dx: dx is the gradient of
+ * act = relu(bn(pre)) (video_frontend.py:31-33: conv1 -> bn1 -> relu feeds conv2), so
+ * sums[c] = sum_pixels g, sums[Cin + c] = sum_pixels g * (pre - mean[c]) * invstd[c] with g = dx * (act > 0) - what
+ * sbl_bn_bwd_reduce(dx, act, pre, ...) would compute in a separate pass over the three tensors.  Stride 1 only. */
+int sbl_conv2d_dgrad_bnstats(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                             int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* act,
+                             const float* pre, const float* mean, const float* invstd, double* sums,
+                             sbl_stream_t stream);
 /* dw_ohwi zeroed by the call, then split-K float atomics */
 int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, int NIMG, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad, sbl_stream_t stream);

@@ -28,6 +28,7 @@ SIGNATURES = {
     "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, I, P],
     "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "sbl_conv2d_dgrad_bnstats": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P],
     "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "sbl_avgpool_fwd": [P, P, I, I, I, P],
     "sbl_avgpool_bwd": [P, P, I, I, I, P],

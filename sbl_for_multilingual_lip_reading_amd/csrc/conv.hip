@@ -93,13 +93,25 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     return 0;
 }
 
-extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
-                                int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
+struct DgradBnStats {       // next BatchNorm backward's reduction riding on the epilogue (EpiStore::bs_*), or all nullptr
+    const float* y;
+    const float* x;
+    const float* mean;
+    const float* inv;
+    double* sums;
+};
+static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                             int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream,
+                             const DgradBnStats& bs) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_conv("sbl_conv2d_dgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(dy && wt && dx && sbl_aligned16(dy) && sbl_aligned16(wt), "sbl_conv2d_dgrad: null/unaligned pointer");
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
     static const int use_classes = getenv("SBL_DGRAD_CLASSES") ? atoi(getenv("SBL_DGRAD_CLASSES")) : 1;   // A/B knob
+    if (bs.sums) {
+        SBL_REQUIRE(stride == 1 && bs.y && bs.x && bs.mean && bs.inv, "sbl_conv2d_dgrad_bnstats: stride-1 convolutions only, all of y / x / mean / invstd");
+        SBL_HIP(hipMemsetAsync(bs.sums, 0, sizeof(double) * 2 * Cin, s));
+    }
     if (stride == 2 && use_classes) {
         // Input pixel (ih, iw) only receives taps with kh = ih + pad (mod 2), kw likewise: 1 + 2 + 2 + 4 of the 9 taps
         // over the four parity classes (3x3), or the even/even class alone (1x1).  One dense implicit GEMM per class
@@ -146,8 +158,13 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
         DenseKCTapList<BN> bl{wt, (long)K, N, Cout, 0ull};                                                     \
         SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                       \
         dim3 grid(sbl_cdiv(N, BN), sbl_cdiv(M, BM), 1);                                                        \
-        EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};        \
-        hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+        if (bs.sums) {                                                                                         \
+            EpiStore<0, true> e{dx, (long)N, nullptr, 0, bs.sums, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0, bs.y, bs.x, bs.mean, bs.inv}; \
+            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, true>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+        } else {                                                                                               \
+            EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};    \
+            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+        }                                                                                                      \
     } while (0)
         if (g_pm_tile == 1 || (!g_pm_tile && N >= 128 && t128 >= 512)) SBL_CONV_DG_PM(128, 128);
         else if (g_pm_tile == 2 || (!g_pm_tile && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512)) SBL_CONV_DG_PM(128, 64);
@@ -160,10 +177,18 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
         DenseKC<BN, true> bl{wt, (long)K, N};                                                                 \
-        EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
-        if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
-            SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                  \
-            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+        if (bs.sums) {                                                                                        \
+            EpiStore<0, true> e{dx, (long)N, nullptr, 0, bs.sums, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, bs.y, bs.x, bs.mean, bs.inv}; \
+            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};              \
+                sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            }                                                                                                 \
+        } else {                                                                                              \
+            EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                               \
+            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};              \
+                sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            }                                                                                                 \
         }                                                                                                     \
     } while (0)
     static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
@@ -174,6 +199,19 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
 #undef SBL_CONV_DG
     SBL_LAUNCH_CHECK("sbl_conv2d_dgrad");
     return 0;
+}
+extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                                int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
+    return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
+                             DgradBnStats{nullptr, nullptr, nullptr, nullptr, nullptr});
+}
+extern "C" int sbl_conv2d_dgrad_bnstats(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                                        int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* act,
+                                        const float* pre, const float* mean, const float* invstd, double* sums,
+                                        sbl_stream_t stream) {
+    SBL_REQUIRE(act && pre && mean && invstd && sums, "sbl_conv2d_dgrad_bnstats: null statistics operand");
+    return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
+                             DgradBnStats{act, pre, mean, invstd, sums});
 }
 
 extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int NIMG, int H, int W, int Cin, int Cout,
@@ -205,17 +243,25 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
         EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
         sbl_launch_gemm<DenseMC<BM, true>, ConvGatherMC<BN>, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s, sc); \
     } while (0)
+    static const int pm_wg_tile = getenv("SBL_PM_WG_TILE") ? atoi(getenv("SBL_PM_WG_TILE")) : 128;   // A/B knob
     if (conv_pm_ok(Ho, Wo, KH, stride) && big && M >= 128 && Cin % 128 == 0) {
-        // one tap per 128-wide tile of the (tap, ci) axis: contract only over the pixels that tap can reach
-        const long tiles = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
-        int splits = (int)((wg_target + tiles - 1) / tiles);
-        if (splits > K / 256) splits = K / 256;
-        if (splits < 1) splits = 1;
-        DenseMCPM<128> al{dy, (long)Cout, M, NIMG, Ho, Wo, PmRect{0, 0, 1, 0, 0}};
-        ConvGatherMCPM<128> bl{x, g, N, PmRect{0, 0, 1, 0, 0}};
-        EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};
-        hipLaunchKernelGGL((sbl_conv_pm_wgrad_kernel<DenseMCPM<128>, ConvGatherMCPM<128>, EpiStore<2, false>, 128, 128>),
-                           dim3(sbl_cdiv(M, 128), sbl_cdiv(N, 128), splits), dim3(256), 0, s, al, bl, e, sc, M, N);
+        // one tap per tile of the (tap, ci) axis: contract only over the pixels that tap can reach
+#define SBL_CONV_WG_PM(T)                                                                                     \
+    do {                                                                                                      \
+        const long tiles = (long)sbl_cdiv(M, T) * sbl_cdiv(N, T);                                             \
+        const int target = (T == 128) ? wg_target : 2 * wg_target;                                            \
+        int splits = (int)((target + tiles - 1) / tiles);                                                     \
+        if (splits > K / 256) splits = K / 256;                                                               \
+        if (splits < 1) splits = 1;                                                                           \
+        DenseMCPM<T> al{dy, (long)Cout, M, NIMG, Ho, Wo, PmRect{0, 0, 1, 0, 0}};                              \
+        ConvGatherMCPM<T> bl{x, g, N, PmRect{0, 0, 1, 0, 0}};                                                 \
+        EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
+        hipLaunchKernelGGL((sbl_conv_pm_wgrad_kernel<DenseMCPM<T>, ConvGatherMCPM<T>, EpiStore<2, false>, T, T>), \
+                           dim3(sbl_cdiv(M, T), sbl_cdiv(N, T), splits), dim3(256), 0, s, al, bl, e, sc, M, N); \
+    } while (0)
+        if (pm_wg_tile == 64) SBL_CONV_WG_PM(64);
+        else SBL_CONV_WG_PM(128);
+#undef SBL_CONV_WG_PM
         SBL_LAUNCH_CHECK("sbl_conv2d_wgrad(pm)");
         return 0;
     }

@@ -636,6 +636,13 @@ struct EpiStore {
     // (ca x cb) is pixel (2a + ph, 2b + pw) of the (cH x cW) image; cmap == 0: row m is output row m;
     // cmap == 2 (position-major rows): GEMM row m = pos * ca + img is output row img * cb + pos
     int cmap, ca, cb, cH, cW, cph, cpw;
+    // STATS with bs_y set: instead of (sum v, sum v^2) the columns reduce the two sums of the NEXT BatchNorm backward
+    // over this launch's output, g = v * (bs_y > 0) and g * (bs_x - bs_mean) * bs_inv (bs_y / bs_x laid out like C): the
+    // input gradient of conv2 is the output gradient of relu(bn1(.)), so bn1's reduction pass rides on this epilogue.
+    const float* bs_y;
+    const float* bs_x;
+    const float* bs_mean;
+    const float* bs_inv;
     __device__ __forceinline__ long row_off(int m) const {
         if (!cmap) return (long)m * ldc;
         if (cmap == 2) {
@@ -651,6 +658,11 @@ struct EpiStore {
                                          float& s1, float& s2) const {
         if (n >= N) return;
         const float b = bias ? bias[n] : 0.f;
+        float bmu = 0.f, bis = 0.f;
+        if (STATS && bs_y) {
+            bmu = bs_mean[n];
+            bis = bs_inv[n];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -658,13 +670,20 @@ struct EpiStore {
                 float v = a[r] + b;
                 if (relu) v = fmaxf(v, 0.f);
                 if (relu_mask) v = relu_mask[(long)m * ldm + n] > 0.f ? v : 0.f;
-                float* q = C + row_off(m) + n;
+                const long o = row_off(m) + n;
+                float* q = C + o;
                 if (MODE == 0) *q = v;
                 else if (MODE == 1) *q += v;
                 else atomicAdd(q, v);
                 if (STATS) {
-                    s1 += v;
-                    s2 += v * v;
+                    if (bs_y) {
+                        const float g = bs_y[o] > 0.f ? v : 0.f;
+                        s1 += g;
+                        s2 += g * ((bs_x[o] - bmu) * bis);
+                    } else {
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
             }
         }

@@ -122,6 +122,8 @@ CONV_WGRAD_SIDE = os.environ.get("SBL_CONV_WGRAD_SIDE", "1") != "0"
 # the second stream also carries the merged decoder weight-gradient GEMMs during the frontend backward; only every
 # k-th trunk dW goes there so that neither stream becomes the longer one
 CONV_WGRAD_SIDE_EVERY = int(os.environ.get("SBL_CONV_WGRAD_SIDE_EVERY", "1"))
+# bn1's backward reduction in the epilogue of conv2's input-gradient convolution (A/B knob)
+FUSE_BN_REDUCE = os.environ.get("SBL_FUSE_BN_REDUCE", "1") != "0"
 _side_join_state = {}      # per device: nn.DataParallel drives one replica per device from its own thread
 
 
@@ -1021,7 +1023,12 @@ class ConvBNFn(torch.autograd.Function):
     video_frontend.py:28-41,69-71.  The BN batch statistics are reduced in the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, relu, stride, training, momentum, eps):
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, relu, stride, training, momentum, eps, box_out=None,
+                box_in=None):
+        """box_out / box_in (dicts or None) link conv1 -> bn1 -> relu to the conv2 that consumes it (BasicBlock,
+        video_frontend.py:31-35): this node publishes (pre-BN output, mean, invstd) in box_out; the consumer, given the same
+        dict as box_in, computes bn1's backward reduction in the epilogue of its input-gradient convolution
+        (sbl_conv2d_dgrad_bnstats) and leaves the sums there, so this node's backward skips its reduction pass."""
         _need_cuda(x, w, gamma, beta)
         x = x.contiguous()
         NIMG, H, W, Cin = x.shape
@@ -1032,7 +1039,7 @@ class ConvBNFn(torch.autograd.Function):
         dev = x.device
         w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         # the input-gradient layout [Cin][kh][kw][Cout] is packed by the same launch and kept for backward
-        w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if (training and x.requires_grad and torch.is_grad_enabled()) else None
+        w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if (training and ctx.needs_input_grad[0]) else None
         call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
         conv = torch.empty(NIMG, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         mean = torch.empty(Cout, device=dev, dtype=torch.float32)
@@ -1054,6 +1061,13 @@ class ConvBNFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, conv, y if relu else None, mean, invstd, gamma, w_dg)
         ctx.cfg = (relu, stride, pad, training, res is not None)
         ctx.gb_bn = (_gbuf(gamma), _gbuf(beta))
+        ctx.box_out = ctx.box_in = None
+        if FUSE_BN_REDUCE and training:      # (grad mode is off inside Function.forward; backward only runs if a tape exists)
+            if box_out is not None and relu and res is None:
+                box_out.update(conv=conv, mean=mean, invstd=invstd, act=y)
+                ctx.box_out = box_out
+            if box_in is not None and stride == 1 and box_in.get("act") is not None and box_in["act"].data_ptr() == x.data_ptr():
+                ctx.box_in = box_in
         return y
 
     @staticmethod
@@ -1067,9 +1081,14 @@ class ConvBNFn(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous()
         rows = conv.numel() // Cout
-        sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-        call("sbl_bn_bwd_reduce", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(sums), rows, Cout, int(relu),
-             _workspace().data_ptr(), WS_BYTES, _s())
+        box = ctx.box_out
+        if box is not None and box.get("sums") is not None and box.get("dx_ptr") == dy.data_ptr():
+            sums = box.pop("sums")           # reduced in the epilogue of the consumer's input-gradient convolution
+            box.clear()
+        else:
+            sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+            call("sbl_bn_bwd_reduce", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(sums), rows, Cout, int(relu),
+                 _workspace().data_ptr(), WS_BYTES, _s())
         dconv = torch.empty_like(conv)
         dres = torch.empty_like(conv) if has_res else None
         if ctx.gb_bn[0] is not None and ctx.gb_bn[1] is not None:      # persistent gradient buffers: += in the kernel
@@ -1088,8 +1107,15 @@ class ConvBNFn(torch.autograd.Function):
                 w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
                 call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
             dx = torch.empty_like(x)
-            call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
-                 _workspace().data_ptr(), WS_BYTES, _s())
+            bi = ctx.box_in
+            if bi is not None and bi.get("conv") is not None:
+                nsums = torch.empty(2 * Cin, device=dev, dtype=torch.float64)
+                call("sbl_conv2d_dgrad_bnstats", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                     _workspace().data_ptr(), WS_BYTES, _p(x), _p(bi["conv"]), _p(bi["mean"]), _p(bi["invstd"]), _p(nsums), _s())
+                bi["sums"], bi["dx_ptr"] = nsums, dx.data_ptr()
+            else:
+                call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                     _workspace().data_ptr(), WS_BYTES, _s())
         gw = _gbuf(w)
         _side_join = _side_join_for_current_device()
         _side_join["n"] += 1
@@ -1107,15 +1133,15 @@ class ConvBNFn(torch.autograd.Function):
             x.record_stream(side)
             dconv.record_stream(side)
             _arm_side_join()
-            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
         dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
         if gw is not None:
             call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
-            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
         dw = torch.empty_like(w)
         call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(dw), Cout, Cin, KH, KW, 0, _s())
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 class AvgPoolFn(torch.autograd.Function):

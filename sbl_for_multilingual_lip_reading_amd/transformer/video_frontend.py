@@ -17,12 +17,12 @@ def conv3x3(in_planes, out_planes, stride=1):
                      padding=1, bias=False)
 
 
-def _conv_bn(x, conv, bn, res, relu, training):
+def _conv_bn(x, conv, bn, res, relu, training, box_out=None, box_in=None):
     """conv -> BatchNorm2d -> (+res) -> (ReLU), NHWC, one tape node; BN side effects like nn.BatchNorm2d."""
     if training:
         bn.num_batches_tracked.add_(1)
     return ops.ConvBNFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu,
-                              conv.stride[0], training, bn.momentum, bn.eps)
+                              conv.stride[0], training, bn.momentum, bn.eps, box_out, box_in)
 
 
 class BasicBlock(nn.Module):
@@ -40,12 +40,13 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         # video_frontend.py:28-41 on NHWC activations
-        out = _conv_bn(x, self.conv1, self.bn1, None, True, self.training)
+        box = {}      # lets conv2's backward do bn1's reduction pass in its epilogue (ops.ConvBNFn)
+        out = _conv_bn(x, self.conv1, self.bn1, None, True, self.training, box_out=box)
         if self.downsample is not None:
             residual = _conv_bn(x, self.downsample[0], self.downsample[1], None, False, self.training)
         else:
             residual = x
-        return _conv_bn(out, self.conv2, self.bn2, residual, True, self.training)
+        return _conv_bn(out, self.conv2, self.bn2, residual, True, self.training, box_in=box)
 
 
 class ResNet(nn.Module):

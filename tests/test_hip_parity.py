@@ -205,6 +205,34 @@ def test_conv2d_fwd_dgrad_wgrad(ops, NIMG, H, W, Cin, Cout, k, stride):
     assert relerr(dw, 2 * w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("NIMG,H,W,C,Cout", [(40, 22, 22, 64, 64), (20, 11, 11, 128, 128), (130, 6, 6, 256, 256), (150, 3, 3, 512, 512)])
+def test_dgrad_epilogue_reduces_the_next_batchnorm_backward(ops, NIMG, H, W, C, Cout):
+    """sbl_conv2d_dgrad_bnstats: same dx as sbl_conv2d_dgrad (bit for bit) and the two per-channel sums that
+    sbl_bn_bwd_reduce computes from (dx, act, pre) in a separate pass."""
+    dy = U("bs_dy%d%d" % (H, C), (NIMG, H, W, Cout)).to(DEV)
+    w = U("bs_w%d%d" % (H, C), (Cout, C, 3, 3), 0.1).to(DEV)
+    pre = U("bs_pre%d%d" % (H, C), (NIMG, H, W, C)).to(DEV)
+    mean = U("bs_mu%d" % C, (C,), 0.1).to(DEV)
+    inv = (U("bs_is%d" % C, (C,), 0.2) + 1.0).to(DEV)
+    act = ((pre - mean) * inv).clamp_min(0).contiguous()
+    w_ohwi, w_dg = torch.empty(Cout, 3, 3, C, device=DEV), torch.empty(C, 3, 3, Cout, device=DEV)
+    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, C, 3, 3, ops._s())
+    ws = ops._workspace()
+    dx0, dx1 = torch.empty(NIMG, H, W, C, device=DEV), torch.empty(NIMG, H, W, C, device=DEV)
+    ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx0.data_ptr(), NIMG, H, W, C, Cout, 3, 3, 1, 1, ws.data_ptr(), ops.WS_BYTES, ops._s())
+    sums = torch.full((2 * C,), float("nan"), device=DEV, dtype=torch.float64)
+    ops.call("sbl_conv2d_dgrad_bnstats", dy.data_ptr(), w_dg.data_ptr(), dx1.data_ptr(), NIMG, H, W, C, Cout, 3, 3, 1, 1, ws.data_ptr(),
+             ops.WS_BYTES, act.data_ptr(), pre.data_ptr(), mean.data_ptr(), inv.data_ptr(), sums.data_ptr(), ops._s())
+    assert torch.equal(dx0, dx1)
+    ref = torch.empty(2 * C, device=DEV, dtype=torch.float64)
+    ops.call("sbl_bn_bwd_reduce", dx0.data_ptr(), act.data_ptr(), pre.data_ptr(), mean.data_ptr(), inv.data_ptr(), ref.data_ptr(),
+             NIMG * H * W, C, 1, ws.data_ptr(), ops.WS_BYTES, ops._s())
+    g = dx0.double() * (act > 0)
+    exact = torch.cat([g.sum((0, 1, 2)), (g * ((pre.double() - mean.double()) * inv.double())).sum((0, 1, 2))])
+    scale = float(exact.abs().max())
+    assert float((sums - exact).abs().max()) < 2e-5 * scale and float((ref - exact).abs().max()) < 2e-5 * scale
+
+
 # --------------------------------------------------------------------------- stem
 @pytest.mark.parametrize("N,T,H,W", [(2, 6, 32, 32), (1, 3, 88, 88), (2, 2, 24, 40), (1, 5, 112, 112)])
 def test_stem_fwd_bwd(ops, N, T, H, W):
