@@ -122,6 +122,8 @@ CONV_WGRAD_SIDE = os.environ.get("SBL_CONV_WGRAD_SIDE", "1") != "0"
 # the second stream also carries the merged decoder weight-gradient GEMMs during the frontend backward; only every
 # k-th trunk dW goes there so that neither stream becomes the longer one
 CONV_WGRAD_SIDE_EVERY = int(os.environ.get("SBL_CONV_WGRAD_SIDE_EVERY", "1"))
+# the decoder's grouped weight-gradient launch joins at the end of backward, not right after it is issued (A/B knob)
+WGRAD_JOIN_AT_END = os.environ.get("SBL_WGRAD_JOIN_AT_END", "1") != "0"
 # bn1's backward reduction in the epilogue of conv2's input-gradient convolution (A/B knob)
 FUSE_BN_REDUCE = os.environ.get("SBL_FUSE_BN_REDUCE", "1") != "0"
 _side_join_state = {}      # per device: nn.DataParallel drives one replica per device from its own thread
