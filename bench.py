@@ -52,7 +52,7 @@ KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm2?_kernel<Dense
                  4: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, false>",
                  5: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, true>",
                  6: r"(sbl_mfma_gemm_kernel<DenseMC<\d+, true>, ConvGatherMC|sbl_conv_pm_wgrad_kernel)", 7: r"sbl_wgrad_group_kernel"}
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_j_pmc_fetch_write_per_kernel.csv")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k_pmc_fetch_write_per_kernel.csv")
 T_START = time.perf_counter()
 
 
@@ -156,13 +156,13 @@ class LaunchRecorder:
                 rows = sum(a[2][i] for i in range(a[1]))
                 fl = sum(2.0 * a[7][p] * a[8][p] * rows for p in range(a[0]))
                 by = sum(4.0 * ((a[7][p] + a[8][p]) * rows + 2 * a[7][p] * a[8][p]) for p in range(a[0]))
-            elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_wgrad"):
+            elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_dgrad_bnstats", "sbl_conv2d_wgrad"):
                 off = 1 if name == "sbl_conv2d_fwd" else 0
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
                 ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
                 by = 4.0 * (nimg * h * w * cin + nimg * ho * wo * cout + cout * kh * kw * cin)
-                desc = "%s n%d %dx%d c%d->%d k%d s%d" % (name[4:], nimg, h, w, cin, cout, kh, stride)
+                desc = "%s n%d %dx%d c%d->%d k%d s%d" % (name[4:].replace("_bnstats", ""), nimg, h, w, cin, cout, kh, stride)
             else:
                 return
             s1 = self.lib.sbl_profile_used()
