@@ -103,7 +103,7 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
     if (!transA || transB) vec = vec && (K % 4 == 0);
     const bool plain = !bias && !relu && !relu_mask;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 2048;   // tuning knob
+    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 4096;   // tuning knob (4352x2048x512: 128x128 tiles 131 us, 64x64 115 us)
     const bool big = (M >= 1024 && N >= 256 && tiles64 >= big_min);
     // split K when the output has too few 64x64 tiles to fill 256 CUs: aim at ~256 workgroups, chunks of at
     // least one 64-deep macro step, at most 8 slices (the last-arriving workgroup reads every slab)
@@ -190,7 +190,7 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_WS_COUNTERS), "sbl_gemm2_f32: workspace unaligned or < 16 KiB");
     const bool vec = sbl_aligned16(A0) && sbl_aligned16(A1) && sbl_aligned16(B0) && sbl_aligned16(B1) && lda % 4 == 0 && ldb % 4 == 0 && K % 8 == 0;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 2048;
+    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 4096;
     const bool big = (M >= 1024 && N >= 256 && 2 * tiles64 >= big_min);
     if (!vec || big) {      // shapes the decoder forward does not produce: two plain launches
         if (int e = sbl_gemm_f32(0, 1, M, N, K, A0, lda, B0, ldb, C0, ldc, bias0, relu, nullptr, 0, 0, nullptr, ws, ws_bytes, stream)) return e;
@@ -324,6 +324,10 @@ struct GroupCommon {
     int nprob, nseg, K;
     int kcum[SBL_MAX_KSEG + 1];
 };
+// ONESEG: every problem's K rows are one contiguous block (the stage-batched decoder backward, the encoder): plain
+// m-contiguous loaders.  The segmented loaders, built in registers from the table, index their pointer arrays
+// dynamically, which puts them in scratch memory (440 bytes per lane) and a scratch read on every operand load.
+template <bool ONESEG>
 __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* __restrict__ table, GroupCommon gc,
                                                               unsigned long long* stamp) {
     // problem of this tile: binary search over tile0 (ascending), workgroup-uniform
@@ -336,21 +340,27 @@ __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* _
     const GroupProb& g = table[lo];
     const int lt = t - g.tile0;
     const int tx = lt % g.tiles_m, ty = lt / g.tiles_m;
-    SegMC<128, true> al, bl;
-#pragma unroll
-    for (int s = 0; s < SBL_MAX_KSEG; ++s) {
-        al.p[s] = g.a[s];
-        bl.p[s] = g.b[s];
-        al.kcum[s] = bl.kcum[s] = gc.kcum[s];
-    }
-    al.kcum[SBL_MAX_KSEG] = bl.kcum[SBL_MAX_KSEG] = gc.K;
-    al.nseg = bl.nseg = gc.nseg;
-    al.ld = g.lda; bl.ld = g.ldb;
-    al.rows = g.M; bl.rows = g.N;
     EpiStore<1, false> e{g.C, g.ldc, nullptr, 0, nullptr, nullptr, 0};
     SplitCtl sc{nullptr, nullptr, g.colsum, stamp};
-    sbl_gemm_tile<SegMC<128, true>, SegMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2>(al, bl, e, sc, g.M, g.N, tx * 128, ty * 128, 0,
-                                                                                        gc.K, 0, 0, 1, ty == 0);
+    if (ONESEG) {
+        DenseMC<128, true> al{g.a[0], g.lda, g.M}, bl{g.b[0], g.ldb, g.N};
+        sbl_gemm_tile<DenseMC<128, true>, DenseMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2>(al, bl, e, sc, g.M, g.N, tx * 128, ty * 128,
+                                                                                              0, gc.K, 0, 0, 1, ty == 0);
+    } else {
+        SegMC<128, true> al, bl;
+#pragma unroll
+        for (int s = 0; s < SBL_MAX_KSEG; ++s) {
+            al.p[s] = g.a[s];
+            bl.p[s] = g.b[s];
+            al.kcum[s] = bl.kcum[s] = gc.kcum[s];
+        }
+        al.kcum[SBL_MAX_KSEG] = bl.kcum[SBL_MAX_KSEG] = gc.K;
+        al.nseg = bl.nseg = gc.nseg;
+        al.ld = g.lda; bl.ld = g.ldb;
+        al.rows = g.M; bl.rows = g.N;
+        sbl_gemm_tile<SegMC<128, true>, SegMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2>(al, bl, e, sc, g.M, g.N, tx * 128, ty * 128, 0,
+                                                                                            gc.K, 0, 0, 1, ty == 0);
+    }
 }
 
 extern "C" long sbl_wgrad_group_table_bytes(int nprob) { return (long)sizeof(GroupProb) * (nprob > 0 ? nprob : 0); }
@@ -403,8 +413,12 @@ extern "C" int sbl_wgrad_group_f32(int nprob, int nseg, const int* seg_rows, con
         hipLaunchKernelGGL(group_write_kernel, dim3(1), dim3(64), 0, s, w, tab, first, count);
     }
     SBL_REQUIRE(tiles < (1L << 30), "sbl_wgrad_group_f32: too many tiles");
-    hipLaunchKernelGGL(sbl_wgrad_group_kernel, dim3((unsigned)tiles), dim3(256), 0, s, (const GroupProb*)tab, gc,
-                       sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
+    if (nseg == 1)
+        hipLaunchKernelGGL(sbl_wgrad_group_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, (const GroupProb*)tab, gc,
+                           sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
+    else
+        hipLaunchKernelGGL(sbl_wgrad_group_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, (const GroupProb*)tab, gc,
+                           sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
     SBL_LAUNCH_CHECK("sbl_wgrad_group_f32");
     return 0;
 }
