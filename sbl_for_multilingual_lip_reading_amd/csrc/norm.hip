@@ -500,8 +500,9 @@ extern "C" int sbl_add_layernorm_bwd(const float* dy, const float* x, const floa
     SBL_REQUIRE(sbl_aligned16(dy) && sbl_aligned16(x) && sbl_aligned16(dz) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma), "sbl_add_layernorm_bwd: unaligned");
     // few, fat workgroups: each ends with 1024 float atomics on the same dgamma/dbeta words
     // 16 rows per workgroup (4 waves x 4 rows in flight); each workgroup ends with 1024 float atomics
+    static const int ln_bwd_blocks = getenv("SBL_LN_BWD_BLOCKS") ? atoi(getenv("SBL_LN_BWD_BLOCKS")) : 128;   // tuning knob
     int blocks = sbl_cdiv(M, 16);
-    if (blocks > 128) blocks = 128;
+    if (blocks > ln_bwd_blocks) blocks = ln_bwd_blocks;
     const int rpb = sbl_cdiv(sbl_cdiv(M, blocks), 16) * 16;
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(sbl_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, x, res,
                        gamma, mean, rstd, dz, dx_drop, dgamma, dbeta, M, rpb, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
