@@ -400,10 +400,16 @@ def main():
     trial_ms = {}
     if mode == "auto":
         n_trial = 2 * len(patterns)
-        trial_ms["graph"] = trial(step_graph, n_trial)
-        trial_ms["eager"] = trial(step_eager, n_trial)
-        mode = "graph" if trial_ms["graph"] <= trial_ms["eager"] else "eager"
-        log(args, "trial: graph %.2f ms, eager %.2f ms -> %s" % (trial_ms["graph"], trial_ms["eager"], mode))
+        for name, fn in (("graph", step_graph), ("eager", step_eager)):
+            try:
+                trial_ms[name] = trial(fn, n_trial)
+            except Exception as e:       # keep the run alive with the other way of issuing the step
+                print("[bench] %s trial failed (%s: %s)" % (name, type(e).__name__, e), file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+        if not trial_ms:
+            raise SystemExit("bench: neither graph replay nor the eager step runs")
+        mode = min(trial_ms, key=trial_ms.get)
+        log(args, "trial: %s -> %s" % (", ".join("%s %.2f ms" % kv for kv in trial_ms.items()), mode))
     if mode == "eager":
         graph, use_split = None, False
         if eager_exchange[0] is None:
