@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="clips per GPU")
     ap.add_argument("--workload", default="full", choices=["full", "frontend"])
+    ap.add_argument("--precision", default="f32", choices=("f32", "bf16x6", "bf16x3", "bf16"),
+                    help="arithmetic of the GEMM / convolution tile engine (include/sbl_hip.h, sbl_set_matmul_precision)")
     ap.add_argument("--no-graph", action="store_true", help="run eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--mode", choices=("auto", "graph", "eager"), default="auto",
                     help="how the step is issued: replayed hipGraphs, eager launches, or (auto) whichever a short trial of both "
@@ -232,6 +234,7 @@ def main():
     from sbl_for_multilingual_lip_reading_amd import _lib, detfill, dp, ops
     from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
     lib = _lib.load()          # fail loudly if the HIP library is missing
+    ops.set_matmul_precision(args.precision)
     rec = LaunchRecorder()
 
     B = args.batch

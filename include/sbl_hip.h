@@ -48,6 +48,17 @@ int sbl_profile_used(void);
 int sbl_profile_last_slot(void);
 int sbl_profile_last_kernel(void);
 
+/* Precision of the matrix products of the tile engine (dense GEMMs and trunk convolutions), process-wide, default 0:
+ *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain — the reference's arithmetic;
+ *   6  every operand split exactly into three bf16 planes on the way into LDS, six bf16 MFMA products per fp32
+ *      product (all plane pairs of weight >= 2^-16), fp32 accumulation: fp32-grade results (dropped terms <= 2^-26
+ *      per product) at 6 x 32 instead of 8 x 64 MFMA cycles per 32x32x16 block;
+ *   3  two planes, three products (~2^-17 per product);   1  plain bf16 inputs with fp32 accumulation — BASELINE
+ *      config 5 "mixed bf16" (fp32 master weights, fp32 accumulate).
+ * Inputs and outputs stay fp32 in memory in every mode.  Returns SBL_ERR_INVALID for any other value. */
+int sbl_set_matmul_precision(int terms);
+int sbl_get_matmul_precision(void);
+
 /* ---------------------------------------------------------------- dense GEMM / Linear
  * C[M,N] (+)= opA(A)[M,K] * opB(B)[K,N], row-major; opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k],
  * opB(B)[k,n] = transB ? B[n*ldb+k] : B[k*ldb+n].  Epilogue: +bias[n], ReLU, or multiply by

@@ -60,6 +60,7 @@ SIGNATURES = {
     "sbl_smoothed_ce_bwd": [P, P, P, P, P, I, I, F, I, P],
     "sbl_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
     "sbl_preprocess_clips": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "sbl_set_matmul_precision": [I],
 }
 
 _lib = None
@@ -83,7 +84,7 @@ def load():
     lib.sbl_last_error.argtypes = []
     lib.sbl_abi_version.restype = c_int
     lib.sbl_abi_version.argtypes = []
-    for name in ("sbl_profile_end", "sbl_profile_last_slot", "sbl_profile_last_kernel", "sbl_profile_used"):
+    for name in ("sbl_profile_end", "sbl_profile_last_slot", "sbl_profile_last_kernel", "sbl_profile_used", "sbl_get_matmul_precision"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = []
     lib.sbl_profile_begin.restype = c_int

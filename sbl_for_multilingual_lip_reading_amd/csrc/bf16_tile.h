@@ -1,0 +1,212 @@
+// bf16 MFMA body of the tile engine (included by mfma_gemm.h; same loaders, split-K and epilogues as the fp32 body).
+//
+// Every fp32 operand element x is split on the way into LDS into NPL bf16 "planes":
+//     p0 = bf16(x)   p1 = bf16(x - p0)   p2 = bf16(x - p0 - p1)        (round-to-nearest-even, v_cvt_pk_bf16_f32)
+// Three planes hold 27 significand bits >= fp32's 24, so x = p0 + p1 + p2 exactly (non-finite x gives NaN planes).
+// A product a*b is then the sum of plane products, each of which v_mfma_f32_32x32x16_bf16 forms exactly (8 x 8
+// significand bits) and accumulates in fp32:
+//     NT = 6 : a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0          dropped terms <= 2^-26 |ab|: fp32-grade results
+//     NT = 3 : a0b0 + a0b1 + a1b0                               ~2^-17 |ab| per product
+//     NT = 1 : a0b0                                             plain bf16 inputs (BASELINE config 5 "mixed bf16")
+// at 6 / 3 / 1 MFMAs of 32 cycles per 32x32x16 block, against 8 fp32 MFMAs of 64 cycles (mfma_f32_32x32x2_f32).
+//
+// LDS images, one per plane and 16-deep K slab:
+//   k-contiguous loaders (kKC): [row][16 k] bf16 = 32 B per row, the two 16-byte halves of a row swapped on odd
+//     8-row groups, so both the 8-byte stores (16 consecutive lanes cover 128 contiguous bytes) and the ds_read_b128
+//     operand reads (lane l: row l&31, k = 8*(l>>5)..+7) are bank-conflict free.
+//   m-contiguous loaders: [16 k][BR m] bf16 with 64 B of padding per row; the MFMA operand (8 consecutive k of one row)
+//     comes out of two ds_read_b64_tr_b16 transposed reads (4 k x 16 m blocks; conflict free with that padding).
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int NT>
+struct BfTerms;
+template <>
+struct BfTerms<1> {
+    static constexpr int NPL = 1, N = 1;
+    __device__ static constexpr int pa(int) { return 0; }
+    __device__ static constexpr int pb(int) { return 0; }
+};
+template <>
+struct BfTerms<3> {
+    static constexpr int NPL = 2, N = 3;
+    __device__ static constexpr int pa(int t) { return t == 1 ? 1 : 0; }     // (0,1) (1,0) (0,0): small terms first
+    __device__ static constexpr int pb(int t) { return t == 0 ? 1 : 0; }
+};
+template <>
+struct BfTerms<6> {
+    static constexpr int NPL = 3, N = 6;
+    __device__ static constexpr int pa(int t) { return t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0; }
+    __device__ static constexpr int pb(int t) { return t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 0 : t == 3 ? 1 : t == 4 ? 0 : 0; }
+};
+
+template <int BR, bool KC>
+struct BfImage {
+    static constexpr int ROW = KC ? 32 : (BR * 2 + 64);       // bytes per image row
+    static constexpr int BYTES = KC ? BR * 32 : 16 * ROW;     // one plane of one 16-deep slab
+};
+
+__device__ __forceinline__ unsigned bf_pack2(float a, float b) {
+    bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// four consecutive fp32 values -> NPL planes of four bf16 (8 bytes each)
+template <int NPL>
+__device__ __forceinline__ void bf_split4(const float4& v, uint2 (&out)[NPL]) {
+    const unsigned a0 = bf_pack2(v.x, v.y), b0 = bf_pack2(v.z, v.w);
+    out[0] = make_uint2(a0, b0);
+    if constexpr (NPL > 1) {
+        const float rx = v.x - bf_lo(a0), ry = v.y - bf_hi(a0), rz = v.z - bf_lo(b0), rw = v.w - bf_hi(b0);
+        const unsigned a1 = bf_pack2(rx, ry), b1 = bf_pack2(rz, rw);
+        out[1] = make_uint2(a1, b1);
+        if constexpr (NPL > 2) {
+            out[2] = make_uint2(bf_pack2(rx - bf_lo(a1), ry - bf_hi(a1)), bf_pack2(rz - bf_lo(b1), rw - bf_hi(b1)));
+        }
+    }
+}
+
+// registers of one loader slab -> its LDS planes (img = plane 0 of the slab; planes are BYTES apart)
+template <class L, int BR, int NPL>
+__device__ __forceinline__ void bf_store(unsigned char* img, const typename L::Regs& r, int tid) {
+    using I = BfImage<BR, L::kKC>;
+    if constexpr (L::kKC) {
+        // thread: rows ps*64 + (tid>>2), k = (tid&3)*4 .. +3
+        const int kq = (tid & 3) * 4;
+#pragma unroll
+        for (int ps = 0; ps < BR / 64; ++ps) {
+            const int row = ps * 64 + (tid >> 2);
+            const int off = row * 32 + ((((kq >> 3) ^ (tid >> 5)) & 1) << 4) + ((kq & 4) << 1);
+            uint2 p[NPL];
+            bf_split4<NPL>(r.v[ps], p);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(img + pl * I::BYTES + off) = p[pl];
+        }
+    } else {
+        // thread: m = (tid % TPR)*4 .. +3, k rows tid/TPR + ps*RPP
+        constexpr int TPR = BR / 4, RPP = 256 / TPR, NP = SBL_BK / RPP;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int off = (tid / TPR + ps * RPP) * I::ROW + (tid % TPR) * 8;
+            uint2 p[NPL];
+            bf_split4<NPL>(r.v[ps], p);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint2*>(img + pl * I::BYTES + off) = p[pl];
+        }
+    }
+}
+
+// MFMA operand of the 32-row block at row base rb: lane l gets row rb + (l&31), k = 8*(l>>5) .. +7
+template <int BR, bool KC>
+__device__ __forceinline__ bf16x8 bf_frag(const unsigned char* img, int rb, int lane) {
+    using I = BfImage<BR, KC>;
+    if constexpr (KC) {
+        const int row = rb + (lane & 31);
+        return *reinterpret_cast<const bf16x8*>(img + row * 32 + ((((lane >> 5) ^ (row >> 3)) & 1) << 4));
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const unsigned char* a = img + (8 * (g >> 1) + q) * I::ROW + (rb + 16 * (g & 1) + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) bf16x4* lds_p;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a + 4 * I::ROW));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int NT>
+__device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
+                                                 int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
+                                                 bool colsum_tile) {
+    using T = BfTerms<NT>;
+    constexpr int NPL = T::NPL;
+    using IA = BfImage<BM, AL::kKC>;
+    using IB = BfImage<BN, BL::kKC>;
+    constexpr int A_SLAB = NPL * IA::BYTES, B_SLAB = NPL * IB::BYTES;
+    constexpr int A_BUF = KU * A_SLAB, BUF = KU * (A_SLAB + B_SLAB);
+    constexpr int MK = KU * SBL_BK;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    constexpr int WM = 4 / WN;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    sbl_stamp_begin(sc.stamp);
+
+    typename AL::State sa;
+    typename BL::State sb;
+    typename AL::Regs ra[KU];
+    typename BL::Regs rb[KU];
+    al.init(sa, m0, tid);
+    bl.init(sb, n0, tid);
+    const bool do_colsum = AL::kColSum && sc.a_colsum != nullptr && colsum_tile;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        al.load(sa, kbeg + u * SBL_BK, kend, ra[u]);
+        bl.load(sb, kbeg + u * SBL_BK, kend, rb[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        if (do_colsum) al.accum(ra[u], cs);
+        bf_store<AL, BM, NPL>(smem + u * A_SLAB, ra[u], tid);
+        bf_store<BL, BN, NPL>(smem + A_BUF + u * B_SLAB, rb[u], tid);
+    }
+    __syncthreads();
+
+    const int arow = wm * (BM / WM), brow = wn * (BN / WN);
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += MK) {
+        const bool has_next = (k0 + MK) < kend;
+        if (has_next) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                al.load(sa, k0 + MK + u * SBL_BK, kend, ra[u]);
+                bl.load(sb, k0 + MK + u * SBL_BK, kend, rb[u]);
+            }
+        }
+        const unsigned char* base = smem + cur * BUF;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            bf16x8 a[NPL][TM], b[NPL][TN];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[pl][i] = bf_frag<BM, AL::kKC>(base + u * A_SLAB + pl * IA::BYTES, arow + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[pl][j] = bf_frag<BN, BL::kKC>(base + A_BUF + u * B_SLAB + pl * IB::BYTES, brow + j * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < T::N; ++t)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[T::pa(t)][i], b[T::pb(t)][j], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) {
+            unsigned char* nb = smem + (cur ^ 1) * BUF;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (do_colsum) al.accum(ra[u], cs);
+                bf_store<AL, BM, NPL>(nb + u * A_SLAB, ra[u], tid);
+                bf_store<BL, BN, NPL>(nb + A_BUF + u * B_SLAB, rb[u], tid);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    sbl_tile_finish<AL, EPI, BM, BN, WN, TM, TN>(al, sa, epi, sc, acc, cs, do_colsum, M, N, m0, n0, tile, z, nz);
+}

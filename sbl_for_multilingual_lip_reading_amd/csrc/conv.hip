@@ -58,24 +58,29 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     } while (0)
     if (conv_pm_ok(Ho, Wo, KH, stride)) {
         // position-major rows: border pixels skip their out-of-bounds taps (mfma_gemm.h, ConvGatherPM)
+#define SBL_KPM_T_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, false>, DenseKCTapList<BN_>, EpiStore<0, true>, BM_, BN_, false, P>
+#define SBL_KPM_F_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, false>, DenseKCTapList<BN_>, EpiStore<0, false>, BM_, BN_, false, P>
 #define SBL_CONV_FWD_PM(BM, BN)                                                                                \
     do {                                                                                                       \
+        constexpr int BM_ = BM, BN_ = BN;                                                                      \
         ConvGatherPM<BM, false> al{x, g, M, 0ull};                                                             \
         DenseKCTapList<BN> bl{w, (long)K, N, Cin, 0ull};                                                       \
         SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_FWD)};                         \
         dim3 grid(sbl_cdiv(N, BN), sbl_cdiv(M, BM), 1);                                                        \
         if (stats) {                                                                                           \
             EpiStore<0, true> e{y, (long)N, nullptr, 0, stats, nullptr, 0, 2, NIMG, Ho * Wo, 0, 0, 0, 0};      \
-            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, false>, DenseKCTapList<BN>, EpiStore<0, true>, BM, BN, false>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+            SBL_PREC_LAUNCH(SBL_KPM_T_, grid, s, al, bl, e, sc, M, N);                                        \
         } else {                                                                                               \
             EpiStore<0, false> e{y, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, Ho * Wo, 0, 0, 0, 0};   \
-            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, false>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, false>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+            SBL_PREC_LAUNCH(SBL_KPM_F_, grid, s, al, bl, e, sc, M, N);                                        \
         }                                                                                                      \
     } while (0)
         if (g_pm_tile == 1 || (!g_pm_tile && N >= 128 && t128 >= 512)) SBL_CONV_FWD_PM(128, 128);
         else if (g_pm_tile == 2 || (!g_pm_tile && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512)) SBL_CONV_FWD_PM(128, 64);
         else SBL_CONV_FWD_PM(64, 64);
 #undef SBL_CONV_FWD_PM
+#undef SBL_KPM_T_
+#undef SBL_KPM_F_
         SBL_LAUNCH_CHECK("sbl_conv2d_fwd(pm)");
         return 0;
     }
@@ -152,24 +157,29 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_dgrad: workspace unaligned or < 16 KiB");
     if (conv_pm_ok(H, W, KH, stride)) {
+#define SBL_KPM_T_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, true>, BM_, BN_, true, P>
+#define SBL_KPM_F_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, false>, BM_, BN_, true, P>
 #define SBL_CONV_DG_PM(BM, BN)                                                                                 \
     do {                                                                                                       \
+        constexpr int BM_ = BM, BN_ = BN;                                                                      \
         ConvGatherPM<BM, true> al{dy, g, M, 0ull};                                                             \
         DenseKCTapList<BN> bl{wt, (long)K, N, Cout, 0ull};                                                     \
         SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                       \
         dim3 grid(sbl_cdiv(N, BN), sbl_cdiv(M, BM), 1);                                                        \
         if (bs.sums) {                                                                                         \
             EpiStore<0, true> e{dx, (long)N, nullptr, 0, bs.sums, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0, bs.y, bs.x, bs.mean, bs.inv}; \
-            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, true>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+            SBL_PREC_LAUNCH(SBL_KPM_T_, grid, s, al, bl, e, sc, M, N);                                        \
         } else {                                                                                               \
             EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};    \
-            hipLaunchKernelGGL((sbl_conv_pm_kernel<ConvGatherPM<BM, true>, DenseKCTapList<BN>, EpiStore<0, false>, BM, BN, true>), grid, dim3(256), 0, s, al, bl, e, sc, M, N); \
+            SBL_PREC_LAUNCH(SBL_KPM_F_, grid, s, al, bl, e, sc, M, N);                                        \
         }                                                                                                      \
     } while (0)
         if (g_pm_tile == 1 || (!g_pm_tile && N >= 128 && t128 >= 512)) SBL_CONV_DG_PM(128, 128);
         else if (g_pm_tile == 2 || (!g_pm_tile && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512)) SBL_CONV_DG_PM(128, 64);
         else SBL_CONV_DG_PM(64, 64);
 #undef SBL_CONV_DG_PM
+#undef SBL_KPM_T_
+#undef SBL_KPM_F_
         SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(pm)");
         return 0;
     }
@@ -246,8 +256,10 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     static const int pm_wg_tile = getenv("SBL_PM_WG_TILE") ? atoi(getenv("SBL_PM_WG_TILE")) : 128;   // A/B knob
     if (conv_pm_ok(Ho, Wo, KH, stride) && big && M >= 128 && Cin % 128 == 0) {
         // one tap per tile of the (tap, ci) axis: contract only over the pixels that tap can reach
+#define SBL_KPMW_(P) sbl_conv_pm_wgrad_kernel<DenseMCPM<T_>, ConvGatherMCPM<T_>, EpiStore<2, false>, T_, T_, P>
 #define SBL_CONV_WG_PM(T)                                                                                     \
     do {                                                                                                      \
+        constexpr int T_ = T;                                                                                 \
         const long tiles = (long)sbl_cdiv(M, T) * sbl_cdiv(N, T);                                             \
         const int target = (T == 128) ? wg_target : 2 * wg_target;                                            \
         int splits = (int)((target + tiles - 1) / tiles);                                                     \
@@ -256,12 +268,12 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
         DenseMCPM<T> al{dy, (long)Cout, M, NIMG, Ho, Wo, PmRect{0, 0, 1, 0, 0}};                              \
         ConvGatherMCPM<T> bl{x, g, N, PmRect{0, 0, 1, 0, 0}};                                                 \
         EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
-        hipLaunchKernelGGL((sbl_conv_pm_wgrad_kernel<DenseMCPM<T>, ConvGatherMCPM<T>, EpiStore<2, false>, T, T>), \
-                           dim3(sbl_cdiv(M, T), sbl_cdiv(N, T), splits), dim3(256), 0, s, al, bl, e, sc, M, N); \
+        SBL_PREC_LAUNCH(SBL_KPMW_, dim3(sbl_cdiv(M, T), sbl_cdiv(N, T), splits), s, al, bl, e, sc, M, N);     \
     } while (0)
         if (pm_wg_tile == 64) SBL_CONV_WG_PM(64);
         else SBL_CONV_WG_PM(128);
 #undef SBL_CONV_WG_PM
+#undef SBL_KPMW_
         SBL_LAUNCH_CHECK("sbl_conv2d_wgrad(pm)");
         return 0;
     }

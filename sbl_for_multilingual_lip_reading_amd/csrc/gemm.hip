@@ -45,6 +45,16 @@ extern "C" int sbl_profile_used(void) { return g_stamp_used; }      // process-w
 extern "C" int sbl_profile_last_kernel(void) { return g_last_kid; }
 extern "C" int sbl_abi_version(void) { return SBL_ABI_VERSION; }
 
+// ------------------------------------------------------------------ matrix-product precision of the tile engine
+int g_sbl_prec = 0;
+extern "C" int sbl_set_matmul_precision(int terms) {
+    SBL_REQUIRE(terms == 0 || terms == 1 || terms == 3 || terms == 6,
+                "sbl_set_matmul_precision: %d (0 = fp32 MFMA, 6 / 3 / 1 = split-bf16 MFMA terms)", terms);
+    g_sbl_prec = terms;
+    return 0;
+}
+extern "C" int sbl_get_matmul_precision(void) { return g_sbl_prec; }
+
 // ------------------------------------------------------------------ dispatch
 template <class AL, class BL, int BM, int BN, int KU>
 static void launch_mode(const AL& al, const BL& bl, float* C, long ldc, const float* bias, int relu,
@@ -327,7 +337,7 @@ struct GroupCommon {
 // ONESEG: every problem's K rows are one contiguous block (the stage-batched decoder backward, the encoder): plain
 // m-contiguous loaders.  The segmented loaders, built in registers from the table, index their pointer arrays
 // dynamically, which puts them in scratch memory (440 bytes per lane) and a scratch read on every operand load.
-template <bool ONESEG>
+template <bool ONESEG, int PREC>
 __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* __restrict__ table, GroupCommon gc,
                                                               unsigned long long* stamp) {
     // problem of this tile: binary search over tile0 (ascending), workgroup-uniform
@@ -344,8 +354,8 @@ __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* _
     SplitCtl sc{nullptr, nullptr, g.colsum, stamp};
     if (ONESEG) {
         DenseMC<128, true> al{g.a[0], g.lda, g.M}, bl{g.b[0], g.ldb, g.N};
-        sbl_gemm_tile<DenseMC<128, true>, DenseMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2>(al, bl, e, sc, g.M, g.N, tx * 128, ty * 128,
-                                                                                              0, gc.K, 0, 0, 1, ty == 0);
+        sbl_gemm_tile<DenseMC<128, true>, DenseMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2, PREC>(al, bl, e, sc, g.M, g.N, tx * 128,
+                                                                                                    ty * 128, 0, gc.K, 0, 0, 1, ty == 0);
     } else {
         SegMC<128, true> al, bl;
 #pragma unroll
@@ -358,8 +368,8 @@ __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* _
         al.nseg = bl.nseg = gc.nseg;
         al.ld = g.lda; bl.ld = g.ldb;
         al.rows = g.M; bl.rows = g.N;
-        sbl_gemm_tile<SegMC<128, true>, SegMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2>(al, bl, e, sc, g.M, g.N, tx * 128, ty * 128, 0,
-                                                                                            gc.K, 0, 0, 1, ty == 0);
+        sbl_gemm_tile<SegMC<128, true>, SegMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2, PREC>(al, bl, e, sc, g.M, g.N, tx * 128,
+                                                                                                  ty * 128, 0, gc.K, 0, 0, 1, ty == 0);
     }
 }
 
@@ -413,12 +423,14 @@ extern "C" int sbl_wgrad_group_f32(int nprob, int nseg, const int* seg_rows, con
         hipLaunchKernelGGL(group_write_kernel, dim3(1), dim3(64), 0, s, w, tab, first, count);
     }
     SBL_REQUIRE(tiles < (1L << 30), "sbl_wgrad_group_f32: too many tiles");
+#define SBL_KG1_(P) sbl_wgrad_group_kernel<true, P>
+#define SBL_KG0_(P) sbl_wgrad_group_kernel<false, P>
     if (nseg == 1)
-        hipLaunchKernelGGL(sbl_wgrad_group_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, (const GroupProb*)tab, gc,
-                           sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
+        SBL_PREC_LAUNCH(SBL_KG1_, dim3((unsigned)tiles), s, (const GroupProb*)tab, gc, sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
     else
-        hipLaunchKernelGGL(sbl_wgrad_group_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, (const GroupProb*)tab, gc,
-                           sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
+        SBL_PREC_LAUNCH(SBL_KG0_, dim3((unsigned)tiles), s, (const GroupProb*)tab, gc, sbl_next_stamp_slot(SBL_KID_SEG_WGRAD));
+#undef SBL_KG1_
+#undef SBL_KG0_
     SBL_LAUNCH_CHECK("sbl_wgrad_group_f32");
     return 0;
 }

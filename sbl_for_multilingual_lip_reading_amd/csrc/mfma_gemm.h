@@ -26,6 +26,7 @@
 template <int BR, bool VEC>
 struct DenseKC {
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     long ld;
     int rows;
@@ -84,6 +85,7 @@ struct DenseKC {
 template <int BR>
 struct DenseKCTaps {
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     long ld;
     int rows;
@@ -139,6 +141,7 @@ struct DenseKCTaps {
 template <int BR>
 struct DenseKCTapList {
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     long ld;
     int rows;
@@ -191,6 +194,7 @@ struct DenseKCTapList {
 template <int BR, bool VEC>
 struct DenseMC {
     static constexpr bool kColSum = true;
+    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     long ld;
     int rows;
@@ -250,6 +254,7 @@ struct DenseMC {
 template <int BR, bool ALIGNED = false>
 struct SegMC {
     static constexpr bool kColSum = true;
+    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p[SBL_MAX_KSEG];
     int kcum[SBL_MAX_KSEG + 1];
     int nseg;
@@ -352,6 +357,7 @@ __device__ __forceinline__ bool conv_src_coord(const ConvGeom& g, int oh, int ow
 template <int BR, bool DGRAD>
 struct ConvGatherKC {
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     ConvGeom g;
     int rows;   // NIMG*OH*OW
@@ -415,6 +421,7 @@ struct ConvGatherKC {
 template <int BR>
 struct ConvGatherMC {
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     ConvGeom g;
     int rows;   // KH*KW*C
@@ -472,6 +479,7 @@ struct ConvGatherMC {
 template <int BR, bool DGRAD>
 struct ConvGatherPM {
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     ConvGeom g;
     int rows;   // NIMG*OH*OW
@@ -534,6 +542,7 @@ struct PmRect {
 template <int BR>
 struct DenseMCPM {            // dY^T: element (co, k') = dy[pixel(k')][co]
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     long ld;
     int rows;
@@ -576,6 +585,7 @@ struct DenseMCPM {            // dY^T: element (co, k') = dy[pixel(k')][co]
 template <int BR>
 struct ConvGatherMCPM {       // x gathered: element ((tap, ci), k') = x[img, oh + dh, ow + dw, ci]
     static constexpr bool kColSum = false;
+    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
     const float* p;
     ConvGeom g;
     int rows;   // KH*KW*C
@@ -714,14 +724,95 @@ struct SplitCtl {
 // each own 64x64 = the LDS-read intensity of a 128x128 tile for the 64-channel layers).
 // The body of one workgroup: output tile at (m0, n0), K range [kbeg, kend); (tile, z, nz) identify the split-K
 // slice for the in-launch slab reduction (nz == 1: no split), colsum_tile: this workgroup feeds a_colsum.
+// Shared tail of a tile: bias-gradient column sums, in-launch split-K slab reduction, epilogue.
+template <class AL, class EPI, int BM, int BN, int WN, int TM, int TN>
+__device__ __forceinline__ void sbl_tile_finish(const AL& al, const typename AL::State& sa, const EPI& epi, const SplitCtl& sc,
+                                                f32x16 (&acc)[TM][TN], const float4& cs, bool do_colsum, int M, int N, int m0,
+                                                int n0, int tile, int z, int nz) {
+    __shared__ int s_last;
+    constexpr int WM = 4 / WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    if (do_colsum) {
+        const int c = al.col(sa);
+        if (c + 0 < M) atomicAdd(sc.a_colsum + c + 0, cs.x);
+        if (c + 1 < M) atomicAdd(sc.a_colsum + c + 1, cs.y);
+        if (c + 2 < M) atomicAdd(sc.a_colsum + c + 2, cs.z);
+        if (c + 3 < M) atomicAdd(sc.a_colsum + c + 3, cs.w);
+    }
+
+    // in-launch split-K reduction (last-arriving workgroup of each tile)
+    if (nz > 1 && sc.slabs != nullptr) {
+        float* mine = sc.slabs + ((long)tile * nz + z) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: hipcc may drop the fence's own wait
+            const int t = __hip_atomic_fetch_add(sc.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == nz - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(sc.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) {
+            sbl_stamp_end(sc.stamp);
+            return;
+        }
+        const float* base = sc.slabs + (long)tile * nz * (BM * BN) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int z = 0; z < nz; ++z) {      // slice order: deterministic sum; 16 independent loads per slice
+                    const float* q = base + (long)z * (BM * BN) + (i * TN + j) * 16 * 256;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = q[r * 256];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
+                }
+            }
+    }
+
+    // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / WM) + i * 32, n, M, N, lane, s1, s2);
+        if (EPI::kStats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32 && n < N) {
+                atomicAdd(epi.stats + n, (double)s1);
+                atomicAdd(epi.stats + N + n, (double)s2);
+            }
+        }
+    }
+    sbl_stamp_end(sc.stamp);
+}
+
 template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN>
-__device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
+__device__ __forceinline__ void sbl_gemm_tile_f32(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
                                               int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
                                               bool colsum_tile) {
     constexpr int MK = KU * SBL_BK;   // macro step
     __shared__ __attribute__((aligned(16))) float As[2][MK][BM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][MK][BN + 4];
-    __shared__ int s_last;
     constexpr int WM = 4 / WN;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -809,84 +900,40 @@ __device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const 
         cur ^= 1;
     }
 
-    if (do_colsum) {
-        const int c = al.col(sa);
-        if (c + 0 < M) atomicAdd(sc.a_colsum + c + 0, cs.x);
-        if (c + 1 < M) atomicAdd(sc.a_colsum + c + 1, cs.y);
-        if (c + 2 < M) atomicAdd(sc.a_colsum + c + 2, cs.z);
-        if (c + 3 < M) atomicAdd(sc.a_colsum + c + 3, cs.w);
-    }
-
-    // in-launch split-K reduction (last-arriving workgroup of each tile)
-    if (nz > 1 && sc.slabs != nullptr) {
-        float* mine = sc.slabs + ((long)tile * nz + z) * (BM * BN);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: hipcc may drop the fence's own wait
-            const int t = __hip_atomic_fetch_add(sc.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == nz - 1);
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(sc.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-            }
-            s_last = last;
-        }
-        __syncthreads();
-        if (!s_last) {
-            sbl_stamp_end(sc.stamp);
-            return;
-        }
-        const float* base = sc.slabs + (long)tile * nz * (BM * BN) + tid;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                for (int z = 0; z < nz; ++z) {      // slice order: deterministic sum; 16 independent loads per slice
-                    const float* q = base + (long)z * (BM * BN) + (i * TN + j) * 16 * 256;
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = q[r * 256];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
-                }
-            }
-    }
-
-    // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / WM) + i * 32, n, M, N, lane, s1, s2);
-        if (EPI::kStats) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32 && n < N) {
-                atomicAdd(epi.stats + n, (double)s1);
-                atomicAdd(epi.stats + N + n, (double)s2);
-            }
-        }
-    }
-    sbl_stamp_end(sc.stamp);
+    sbl_tile_finish<AL, EPI, BM, BN, WN, TM, TN>(al, sa, epi, sc, acc, cs, do_colsum, M, N, m0, n0, tile, z, nz);
 }
+
+#include "bf16_tile.h"
+
+// PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); PREC = 1 / 3 / 6: bf16 MFMA on 1 / 2 / 3 bf16 planes per operand
+// (bf16_tile.h: 6 = every product of an exact 3-way split whose weight is >= 2^-16, i.e. fp32-grade results).
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int PREC = 0>
+__device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
+                                              int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
+                                              bool colsum_tile) {
+    if constexpr (PREC == 0)
+        sbl_gemm_tile_f32<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
+    else
+        sbl_gemm_tile_bf<AL, BL, EPI, BM, BN, KU, WN, PREC>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
+}
+
+// Matrix-product precision of the tile engine (sbl_set_matmul_precision): 0 = fp32 MFMA, 6 / 3 / 1 = bf16 MFMA terms.
+extern int g_sbl_prec;
+#define SBL_PREC_LAUNCH(KERNEL_P, grid, s, ...)                                                         \
+    do {                                                                                                \
+        switch (g_sbl_prec) {                                                                           \
+            case 6: hipLaunchKernelGGL((KERNEL_P(6)), grid, dim3(256), 0, s, __VA_ARGS__); break;       \
+            case 3: hipLaunchKernelGGL((KERNEL_P(3)), grid, dim3(256), 0, s, __VA_ARGS__); break;       \
+            case 1: hipLaunchKernelGGL((KERNEL_P(1)), grid, dim3(256), 0, s, __VA_ARGS__); break;       \
+            default: hipLaunchKernelGGL((KERNEL_P(0)), grid, dim3(256), 0, s, __VA_ARGS__); break;      \
+        }                                                                                               \
+    } while (0)
 
 // XCD-aware tile order (x_off < 0 selects it; the real offset is then -x_off - 1).  Workgroups go to the 8 XCDs
 // round-robin by linear id, each XCD with its own L2.  With the plain (x fastest) order the n-tiles that share one
 // A row block land on different XCDs and every L2 fetches that block again.  Here XCD c works through a contiguous
 // range of the n-fastest tile order, so an A row block is fetched by one L2 and only the (small) B operand by all 8.
-template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2>
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2, int PREC = 0>
 __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
                                                             int kchunk, int x_off) {
     int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
@@ -904,10 +951,9 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
         x_off = -x_off - 1;
     }
     const int kbeg = z * kchunk;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, (x + x_off) * BM, y * BN, kbeg,
-                                               min(K, kbeg + kchunk), y * gridDim.x + x, z, gridDim.z, y == 0);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN, PREC>(al, bl, epi, sc, M, N, (x + x_off) * BM, y * BN, kbeg,
+                                                     min(K, kbeg + kchunk), y * gridDim.x + x, z, gridDim.z, y == 0);
 }
-static const int g_xcd_swizzle = getenv("SBL_XCD_SWIZZLE") ? atoi(getenv("SBL_XCD_SWIZZLE")) : 1;   // A/B knob (same speed, 2.4x fewer fabric-side bytes: tools/bench_gemm7.py under --pmc FETCH_SIZE)
 
 // Two problems of one shape in one launch (the two decoder directions; see SkinnyDual): blockIdx.y in [Y, 2Y) works on
 // the second operand set.  Dense loaders and the plain-store epilogue only.
@@ -917,7 +963,7 @@ struct GemmDual {
     float* C1;
     const float* bias1;
 };
-template <class AL, class BL, class EPI, int BM, int BN, int KU>
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int PREC = 0>
 __global__ __launch_bounds__(256) void sbl_mfma_gemm2_kernel(AL al, BL bl, EPI epi, SplitCtl sc, GemmDual du, int M, int N, int K,
                                                              int kchunk) {
     int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
@@ -941,8 +987,8 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm2_kernel(AL al, BL bl, EPI e
         epi.bias = du.bias1;
     }
     const int kbeg = z * kchunk;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, 2>(al, bl, epi, sc, M, N, x * BM, y * BN, kbeg, min(K, kbeg + kchunk), tile, z,
-                                              gridDim.z, false);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, 2, PREC>(al, bl, epi, sc, M, N, x * BM, y * BN, kbeg, min(K, kbeg + kchunk), tile, z,
+                                                    gridDim.z, false);
 }
 template <class AL, class BL, class EPI, int BM, int BN, int KU>
 static inline void sbl_launch_gemm2(const AL& al, const BL& bl, const EPI& epi, const GemmDual& du, int M, int N, int K, int splits,
@@ -951,7 +997,9 @@ static inline void sbl_launch_gemm2(const AL& al, const BL& bl, const EPI& epi, 
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), 2 * sbl_cdiv(N, BN), nz);
-    hipLaunchKernelGGL((sbl_mfma_gemm2_kernel<AL, BL, EPI, BM, BN, KU>), grid, dim3(256), 0, s, al, bl, epi, sc, du, M, N, K, kchunk);
+#define SBL_K_(P) sbl_mfma_gemm2_kernel<AL, BL, EPI, BM, BN, KU, P>
+    SBL_PREC_LAUNCH(SBL_K_, grid, s, al, bl, epi, sc, du, M, N, K, kchunk);
+#undef SBL_K_
 }
 
 // Position-major convolution tiles (ConvGatherPM x DenseKCTapList): the workgroup's tap list = union of the in-bounds
@@ -970,7 +1018,7 @@ __device__ __forceinline__ unsigned sbl_pm_tap_mask(const ConvGeom& g, int pos) 
 // (Measured and not kept: a persistent grid drawing tiles from an atomic counter to balance the 4 / 6 / 9-tap tiles.
 // With only 1-2 tiles per resident workgroup the per-slot quantisation costs more than the balance gains: layer 3
 // forward 360 -> 454 us, layer 4 390 -> 411 us.)
-template <class AL, class BL, class EPI, int BM, int BN, bool DGRAD>
+template <class AL, class BL, class EPI, int BM, int BN, bool DGRAD, int PREC = 0>
 __global__ __launch_bounds__(256) void sbl_conv_pm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N) {
     // grid = (n-tiles, m-tiles), plain order.  (Measured and not kept: the XCD-aware order of sbl_mfma_gemm_kernel.  It
     // hands each XCD a contiguous range of positions, i.e. mostly one tap count, and the 9-tap XCD then outlasts the
@@ -988,12 +1036,12 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_kernel(AL al, BL bl, EPI epi,
         }
     al.taps = list;
     bl.taps = list;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, m0, blockIdx.x * BN, 0, nt * al.g.C,
-                                             blockIdx.y * gridDim.x + blockIdx.x, 0, 1, false);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2, PREC>(al, bl, epi, sc, M, N, m0, blockIdx.x * BN, 0, nt * al.g.C,
+                                                   blockIdx.y * gridDim.x + blockIdx.x, 0, 1, false);
 }
 // Position-major weight-gradient tiles (DenseMCPM x ConvGatherMCPM, C % BN == 0: one tap per tile); gridDim.z
 // workgroups share the tile's own K' = (in-bounds pixels of its tap) * NIMG evenly and add with float atomics.
-template <class AL, class BL, class EPI, int BM, int BN>
+template <class AL, class BL, class EPI, int BM, int BN, int PREC = 0>
 __global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N) {
     const ConvGeom& g = bl.g;
     // (plain order: the XCD-aware order measured 4 % slower here - 384 -> 400 us on layer 3)
@@ -1015,8 +1063,8 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EP
     if (kbeg >= K) return;
     al.rc = rc;
     bl.rc = rc;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2>(al, bl, epi, sc, M, N, bx * BM, n0, kbeg, min(K, kbeg + kchunk),
-                                             by * gridDim.x + bx, 0, 1, false);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2, PREC>(al, bl, epi, sc, M, N, bx * BM, n0, kbeg, min(K, kbeg + kchunk),
+                                                   by * gridDim.x + bx, 0, 1, false);
 }
 
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>
@@ -1026,7 +1074,9 @@ static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, i
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN>), grid, dim3(256), 0, s, al, bl, epi, sc, M, N, K, kchunk, g_xcd_swizzle ? -1 : 0);
+#define SBL_K_(P) sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN, P>
+    SBL_PREC_LAUNCH(SBL_K_, grid, s, al, bl, epi, sc, M, N, K, kchunk, -1);
+#undef SBL_K_
 }
 
 // Tail splitting.  Every tile of these launches is resident at once, so a launch lasts as long as its fullest CU:
@@ -1051,10 +1101,11 @@ static inline bool sbl_launch_gemm_tailsplit(const AL& al, const BL& bl, const E
     const long need = (long)sizeof(int) * ws_counters + rem * sp * (long)(BM * BN * sizeof(float));
     if (need > ws_bytes) return false;
     SplitCtl sa{nullptr, nullptr, nullptr, sbl_next_stamp_slot(stamp_kid)};
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(XA, Y, 1), dim3(256), 0, s, al, bl, epi, sa, M, N, K, K, g_xcd_swizzle ? -1 : 0);
+#define SBL_K_(P) sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2, P>
+    SBL_PREC_LAUNCH(SBL_K_, dim3(XA, Y, 1), s, al, bl, epi, sa, M, N, K, K, -1);
     SplitCtl sb{(float*)((char*)ws + sizeof(int) * ws_counters), (int*)ws, nullptr, sbl_next_stamp_slot(stamp_kid)};
     const int kchunk = sbl_cdiv(sbl_cdiv(K, sp), MK) * MK;
-    hipLaunchKernelGGL((sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, 2>), dim3(X - XA, Y, sbl_cdiv(K, kchunk)), dim3(256), 0, s, al, bl,
-                       epi, sb, M, N, K, kchunk, g_xcd_swizzle ? -(XA + 1) : XA);
+    SBL_PREC_LAUNCH(SBL_K_, dim3(X - XA, Y, sbl_cdiv(K, kchunk)), s, al, bl, epi, sb, M, N, K, kchunk, -(XA + 1));
+#undef SBL_K_
     return true;
 }

@@ -20,6 +20,22 @@ except ImportError:      # drop-in mode: this directory itself is on sys.path (I
 
 call = _lib.call
 
+_PRECISIONS = {"f32": 0, "bf16x6": 6, "bf16x3": 3, "bf16": 1}
+
+
+def set_matmul_precision(mode):
+    """Arithmetic of every dense GEMM / trunk convolution (include/sbl_hip.h, sbl_set_matmul_precision), process-wide:
+    "f32" exact fp32 MFMA; "bf16x6" exact three-way bf16 split, six bf16 MFMA products, fp32 accumulation (fp32-grade
+    results, the default of bench.py); "bf16x3" two planes / three products; "bf16" plain bf16 inputs (BASELINE config 5)."""
+    if mode not in _PRECISIONS:
+        raise ValueError("matmul precision %r (one of %s)" % (mode, ", ".join(_PRECISIONS)))
+    call("sbl_set_matmul_precision", _PRECISIONS[mode])
+
+
+def get_matmul_precision():
+    v = _lib.load().sbl_get_matmul_precision()
+    return [k for k, t in _PRECISIONS.items() if t == v][0]
+
 
 def _s():
     return torch.cuda.current_stream().cuda_stream

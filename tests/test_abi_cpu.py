@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # ctypes table == header (minus the two non-int helpers)
     helpers = ("sbl_last_error", "sbl_abi_version", "sbl_profile_begin", "sbl_profile_end", "sbl_profile_last_slot",
-               "sbl_profile_last_kernel", "sbl_profile_used", "sbl_wgrad_group_table_bytes")      # bound by hand in _lib.load()
+               "sbl_profile_last_kernel", "sbl_profile_used", "sbl_wgrad_group_table_bytes",
+               "sbl_get_matmul_precision")      # bound by hand in _lib.load()
     assert sorted(_lib.SIGNATURES) == sorted(n for n in names if n not in helpers)
     for h in helpers:
         assert hasattr(lib, h)
@@ -55,6 +56,9 @@ def test_invalid_arguments_are_rejected_on_the_host():
     with pytest.raises(_lib.SblHipError, match="Lq,Lk <= 64"):
         _lib.call("sbl_attention_fwd", None, 64, None, 64, None, 64, None, 64, None, 0, None, 1, 1, 65, 4, 0.125, 0.0,
                   None, 0, None)
+    with pytest.raises(_lib.SblHipError, match="sbl_set_matmul_precision: 2"):
+        _lib.call("sbl_set_matmul_precision", 2)
+    assert _lib.load().sbl_get_matmul_precision() == 0      # the library starts in exact-fp32 mode
     with pytest.raises(_lib.SblHipError, match="D=256"):
         _lib.call("sbl_add_layernorm_fwd", None, None, None, None, None, None, None, 4, 256, 1e-5, 0.0, None, 0, None)
 

@@ -19,12 +19,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["f32", "bf16x6"])
+def ops(request):
+    """Every test runs under both fp32-grade arithmetics of the tile engine: exact fp32 MFMA and the exact three-way
+    bf16 split with six bf16 MFMA products (include/sbl_hip.h, sbl_set_matmul_precision); same tolerances for both."""
     from sbl_for_multilingual_lip_reading_amd import _lib, ops as _ops
     _lib.load()
     assert torch.cuda.is_available()
-    return _ops
+    _ops.set_matmul_precision(request.param)
+    yield _ops
+    _ops.set_matmul_precision("f32")
 
 
 def U(name, shape, s=1.0):
@@ -776,11 +780,19 @@ def test_e2e_matches_oracle_other_seed(ops):
     loss.backward()
     assert maxdiff(pl, ref["pred_l2r"]) < 1e-3 and maxdiff(pr, ref["pred_r2l"]) < 1e-3
     assert abs(loss.item() - rloss.item()) < 1e-3
+    # Gradients: ReLU's derivative jumps at 0, and of the ~3e6 feed-forward pre-activations of this step a few lie within
+    # rounding distance of 0 (density ~1 per unit => ~1 within 3e-7).  Any two fp32-grade evaluations can therefore
+    # disagree on one mask bit, which moves ONE row of that layer's dW1 / db1 by O(1/rows) (2.4e-2 of max observed for
+    # hidden unit 1779 of layer_stack_r2l.0 between the two MFMA modes on this input, everything else of that tensor
+    # equal) and everything upstream of it by ~1e-3.  Hence a per-tensor relative L2 bound plus a loose max bound
+    # here; the reference fixtures (test_e2e_train_step_golden) carry the tight element-wise gradient checks.
     named = dict(m.named_parameters())
     for n, p in named.items():
         if n.startswith("decoder") or n.startswith("encoder"):
             r = sd[n].grad
-            assert maxdiff(p.grad, r) < 2e-3 * float(r.abs().max()) + 2e-6, n
+            g = p.grad.detach().cpu()
+            assert float((g - r).norm()) < 5e-3 * float(r.norm()) + 1e-5, n
+            assert maxdiff(g, r) < 5e-2 * float(r.abs().max()) + 2e-6, n
 
 
 def test_config5_shape_matches_oracle(ops):
