@@ -10,7 +10,8 @@ static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout
     SBL_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cout >= 16, "%s: Cin=%d Cout=%d must be multiples of 16", who, Cin, Cout);
     SBL_REQUIRE((KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0), "%s: only 3x3/pad1 and 1x1/pad0 (got %dx%d pad %d)", who, KH, KW, pad);
     SBL_REQUIRE(stride == 1 || stride == 2, "%s: stride %d", who, stride);
-    SBL_REQUIRE((long)NIMG * H * W * (long)(Cin > Cout ? Cin : Cout) < (1L << 31), "%s: tensor too large for 32-bit pixel index", who);
+    SBL_REQUIRE(sbl_fits_u32((long)NIMG * H * W * (long)(Cin > Cout ? Cin : Cout)), "%s: tensor spans more than 2 GiB (buffer descriptor range)", who);
+    SBL_REQUIRE((long)NIMG * H * W < (1L << 24) && Cin < (1 << 16) && Cout < (1 << 16), "%s: more than 2^24 pixels (24-bit index arithmetic in the gathers)", who);
     return 0;
 }
 static inline int out_dim(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
@@ -35,6 +36,7 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
     const int M = NIMG * Ho * Wo, N = Cout, K = KH * KW * Cin;
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    sbl_geom_finish(g);
     if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_fwd: workspace unaligned or < 16 KiB");
@@ -112,12 +114,11 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     if (int e = check_conv("sbl_conv2d_dgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(dy && wt && dx && sbl_aligned16(dy) && sbl_aligned16(wt), "sbl_conv2d_dgrad: null/unaligned pointer");
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
-    static const int use_classes = getenv("SBL_DGRAD_CLASSES") ? atoi(getenv("SBL_DGRAD_CLASSES")) : 1;   // A/B knob
     if (bs.sums) {
         SBL_REQUIRE(stride == 1 && bs.y && bs.x && bs.mean && bs.inv, "sbl_conv2d_dgrad_bnstats: stride-1 convolutions only, all of y / x / mean / invstd");
         SBL_HIP(hipMemsetAsync(bs.sums, 0, sizeof(double) * 2 * Cin, s));
     }
-    if (stride == 2 && use_classes) {
+    if (stride == 2) {
         // Input pixel (ih, iw) only receives taps with kh = ih + pad (mod 2), kw likewise: 1 + 2 + 2 + 4 of the 9 taps
         // over the four parity classes (3x3), or the even/even class alone (1x1).  One dense implicit GEMM per class
         // (rows = the class's pixels, k = its taps) does 1/4 of the work of gathering zeros for the other taps.
@@ -126,6 +127,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {
                 ConvGeom g{NIMG, (H - ph + 1) / 2, (W - pw + 1) / 2, Ho, Wo, Cout, KH, KW, stride, pad, 1, ph, pw, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                sbl_geom_finish(g);
                 int lin[4] = {0, 0, 0, 0};
                 for (int kh = 0; kh < KH; ++kh)
                     for (int kw = 0; kw < KW; ++kw)
@@ -154,6 +156,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     }
     const int M = NIMG * H * W, N = Cin, K = KH * KW * Cout;
     ConvGeom g{NIMG, H, W, Ho, Wo, Cout, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    sbl_geom_finish(g);
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_dgrad: workspace unaligned or < 16 KiB");
     if (conv_pm_ok(H, W, KH, stride)) {
@@ -232,6 +235,7 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
     const int M = Cout, N = KH * KW * Cin, K = NIMG * Ho * Wo;   // reduce over output pixels
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    sbl_geom_finish(g);
     SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * N, s));
     // split the pixel reduction: 128x128 tiles for the 128+-channel layers (twice the flops per staged byte), 64x64
     // otherwise, and 6 / 12 workgroups per CU so that the uneven last chunks and the atomic epilogues of one
@@ -265,8 +269,8 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
         int splits = (int)((target + tiles - 1) / tiles);                                                     \
         if (splits > K / 256) splits = K / 256;                                                               \
         if (splits < 1) splits = 1;                                                                           \
-        DenseMCPM<T> al{dy, (long)Cout, M, NIMG, Ho, Wo, PmRect{0, 0, 1, 0, 0}};                              \
-        ConvGatherMCPM<T> bl{x, g, N, PmRect{0, 0, 1, 0, 0}};                                                 \
+        DenseMCPM<T> al{dy, (long)Cout, M, NIMG, Ho, Wo, g.fdNIMG, PmRect{0, 0, 1, 0, 0, 1.f}};                              \
+        ConvGatherMCPM<T> bl{x, g, N, PmRect{0, 0, 1, 0, 0, 1.f}};                                              \
         EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
         SBL_PREC_LAUNCH(SBL_KPMW_, dim3(sbl_cdiv(M, T), sbl_cdiv(N, T), splits), s, al, bl, e, sc, M, N);     \
     } while (0)

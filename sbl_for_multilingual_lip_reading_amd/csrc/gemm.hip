@@ -111,6 +111,10 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
     // float4 path: every row start 16-byte aligned and, for k-contiguous operands, K % 4 == 0
     bool vec = sbl_aligned16(A) && sbl_aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     if (!transA || transB) vec = vec && (K % 4 == 0);
+    if (transA) vec = vec && (M % 4 == 0);          // m-contiguous operands: whole float4s along the row axis
+    if (!transB) vec = vec && (N % 4 == 0);
+    SBL_REQUIRE(sbl_fits_u32((transA ? (long)K : (long)M) * lda) && sbl_fits_u32((transB ? (long)N : (long)K) * ldb),
+                "sbl_gemm_f32: operand spans more than 2 GiB (buffer descriptor range)");
     const bool plain = !bias && !relu && !relu_mask;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
     static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 4096;   // tuning knob (4352x2048x512: 128x128 tiles 131 us, 64x64 115 us)
@@ -199,6 +203,7 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     SBL_REQUIRE(lda >= K && ldb >= K && ldc >= N, "sbl_gemm2_f32: leading dimension too small (lda=%ld ldb=%ld ldc=%ld)", lda, ldb, ldc);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_WS_COUNTERS), "sbl_gemm2_f32: workspace unaligned or < 16 KiB");
     const bool vec = sbl_aligned16(A0) && sbl_aligned16(A1) && sbl_aligned16(B0) && sbl_aligned16(B1) && lda % 4 == 0 && ldb % 4 == 0 && K % 8 == 0;
+    SBL_REQUIRE(sbl_fits_u32((long)M * lda) && sbl_fits_u32((long)N * ldb), "sbl_gemm2_f32: operand spans more than 2 GiB (buffer descriptor range)");
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
     static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 4096;
     const bool big = (M >= 1024 && N >= 256 && 2 * tiles64 >= big_min);
@@ -405,6 +410,8 @@ extern "C" int sbl_wgrad_group_f32(int nprob, int nseg, const int* seg_rows, con
         for (int i = 0; i < count; ++i) {
             const int p = first + i;
             GroupProb& g = w.p[i];
+            SBL_REQUIRE(M[p] % 4 == 0 && N[p] % 4 == 0 && sbl_fits_u32(K * lda[p]) && sbl_fits_u32(K * ldb[p]),
+                        "sbl_wgrad_group_f32: problem %d: M=%d / N=%d must be multiples of 4 and the operands at most 2 GiB", p, M[p], N[p]);
             SBL_REQUIRE(M[p] > 0 && N[p] > 0 && C[p] && lda[p] >= M[p] && ldb[p] >= N[p] && ldc[p] >= N[p] && lda[p] % 4 == 0 && ldb[p] % 4 == 0,
                         "sbl_wgrad_group_f32: problem %d has bad dims M=%d N=%d lda=%ld ldb=%ld ldc=%ld", p, M[p], N[p], lda[p], ldb[p], ldc[p]);
             for (int t = 0; t < SBL_MAX_KSEG; ++t) {

@@ -19,615 +19,7 @@
 #pragma once
 #include "sbl_common.h"
 
-#define SBL_BK 16
-
-// ------------------------------------------------------------------ loaders
-// Dense, k-contiguous: element (r,k) at p[r*ld + k].  Used for X[M,K] and W[N,K] of Linear.
-template <int BR, bool VEC>
-struct DenseKC {
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    long ld;
-    int rows;
-    struct State {
-        const float* rp[BR / 64];
-        bool ok[BR / 64];
-        int kq;
-    };
-    struct Regs {
-        float4 v[BR / 64];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.kq = (tid & 3) * 4;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            int r = r0 + ps * 64 + (tid >> 2);
-            s.ok[ps] = r < rows;
-            s.rp[ps] = p + (long)(s.ok[ps] ? r : 0) * ld;
-        }
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-        const int k = k0 + s.kq;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s.ok[ps]) {
-                if (VEC) {
-                    if (k < kend) v = *reinterpret_cast<const float4*>(s.rp[ps] + k);
-                } else {
-                    if (k + 0 < kend) v.x = s.rp[ps][k + 0];
-                    if (k + 1 < kend) v.y = s.rp[ps][k + 1];
-                    if (k + 2 < kend) v.z = s.rp[ps][k + 2];
-                    if (k + 3 < kend) v.w = s.rp[ps][k + 3];
-                }
-            }
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            const int row = ps * 64 + (tid >> 2);
-            lds[s.kq + 0][row] = r.v[ps].x;
-            lds[s.kq + 1][row] = r.v[ps].y;
-            lds[s.kq + 2][row] = r.v[ps].z;
-            lds[s.kq + 3][row] = r.v[ps].w;
-        }
-    }
-};
-
-// Dense k-contiguous rows whose k axis is a SUBSET of C-wide blocks of the stored row: GEMM-k block t (k in
-// [t*C, (t+1)*C)) lives at stored block lin[t].  Used for the weight operand of the parity-class input gradients
-// (the class's taps out of the [Cin][KH*KW][Cout] rows).  C % 16 == 0, so a BK slice never straddles a block.
-template <int BR>
-struct DenseKCTaps {
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    long ld;
-    int rows;
-    int C;
-    int lin[4];
-    struct State {
-        const float* rp[BR / 64];
-        bool ok[BR / 64];
-        int kq;
-    };
-    struct Regs {
-        float4 v[BR / 64];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.kq = (tid & 3) * 4;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            int r = r0 + ps * 64 + (tid >> 2);
-            s.ok[ps] = r < rows;
-            s.rp[ps] = p + (long)(s.ok[ps] ? r : 0) * ld;
-        }
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-        const int t = k0 / C;              // block-uniform
-        int l = lin[0];
-#pragma unroll
-        for (int u = 1; u < 4; ++u)
-            if (u == t) l = lin[u];
-        const int k = l * C + (k0 - t * C) + s.kq;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s.ok[ps] && k0 < kend) v = *reinterpret_cast<const float4*>(s.rp[ps] + k);
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            const int row = ps * 64 + (tid >> 2);
-            lds[s.kq + 0][row] = r.v[ps].x;
-            lds[s.kq + 1][row] = r.v[ps].y;
-            lds[s.kq + 2][row] = r.v[ps].z;
-            lds[s.kq + 3][row] = r.v[ps].w;
-        }
-    }
-};
-
-// Same, with the block list packed 4 bits per entry (up to 9 blocks) and set per workgroup: the weight operand of the
-// position-major convolutions below, whose tiles contract only over the taps that can be in bounds for their pixels.
-template <int BR>
-struct DenseKCTapList {
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    long ld;
-    int rows;
-    int C;
-    unsigned long long taps;
-    struct State {
-        const float* rp[BR / 64];
-        bool ok[BR / 64];
-        int kq;
-    };
-    struct Regs {
-        float4 v[BR / 64];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.kq = (tid & 3) * 4;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            int r = r0 + ps * 64 + (tid >> 2);
-            s.ok[ps] = r < rows;
-            s.rp[ps] = p + (long)(s.ok[ps] ? r : 0) * ld;
-        }
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-        const int t = k0 / C;              // block-uniform
-        const int l = (int)((taps >> (4 * t)) & 15ull);
-        const int k = l * C + (k0 - t * C) + s.kq;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s.ok[ps] && k0 < kend) v = *reinterpret_cast<const float4*>(s.rp[ps] + k);
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            const int row = ps * 64 + (tid >> 2);
-            lds[s.kq + 0][row] = r.v[ps].x;
-            lds[s.kq + 1][row] = r.v[ps].y;
-            lds[s.kq + 2][row] = r.v[ps].z;
-            lds[s.kq + 3][row] = r.v[ps].w;
-        }
-    }
-};
-
-// Dense, m-contiguous: element (r,k) at p[k*ld + r].  Used for dY^T / X in weight-gradient
-// GEMMs and for W[K,N] in input-gradient GEMMs.
-template <int BR, bool VEC>
-struct DenseMC {
-    static constexpr bool kColSum = true;
-    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    long ld;
-    int rows;
-    static constexpr int TPR = BR / 4;           // threads per k-row
-    static constexpr int RPP = 256 / TPR;        // k-rows per pass
-    static constexpr int NP = SBL_BK / RPP;      // passes
-    struct State {
-        int c, kr;
-    };
-    struct Regs {
-        float4 v[NP];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.c = r0 + (tid % TPR) * 4;
-        s.kr = tid / TPR;
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int k = k0 + s.kr + ps * RPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend) {
-                const float* q = p + (long)k * ld + s.c;
-                if (VEC && s.c + 3 < rows) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (s.c + 0 < rows) v.x = q[0];
-                    if (s.c + 1 < rows) v.y = q[1];
-                    if (s.c + 2 < rows) v.z = q[2];
-                    if (s.c + 3 < rows) v.w = q[3];
-                }
-            }
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs& r, float4& cs) const {   // column sums over k of this operand
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            cs.x += r.v[ps].x; cs.y += r.v[ps].y; cs.z += r.v[ps].z; cs.w += r.v[ps].w;
-        }
-    }
-    __device__ __forceinline__ int col(const State& s) const { return s.c; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
-    }
-};
-
-// Segmented m-contiguous operand: the GEMM-k axis is the concatenation of up to 16 row blocks that live in
-// different tensors (the per-stage activations / gradients of one decoder layer): element (r, k) = p[s][(k -
-// kcum[s])*ld + r] with s the segment containing k.  Lets one weight-gradient GEMM contract over all decoder
-// stages of a step (K ~ 4352 rows) instead of one skinny GEMM per stage.
-#define SBL_MAX_KSEG 16
-// ALIGNED: every segment length is a multiple of SBL_BK, so a BK-deep slice lies in one segment and the segment
-// lookup is workgroup-uniform (scalar unit) instead of 15 compare/select pairs per lane per load.
-template <int BR, bool ALIGNED = false>
-struct SegMC {
-    static constexpr bool kColSum = true;
-    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p[SBL_MAX_KSEG];
-    int kcum[SBL_MAX_KSEG + 1];
-    int nseg;
-    long ld;
-    int rows;
-    static constexpr int TPR = BR / 4;
-    static constexpr int RPP = 256 / TPR;
-    static constexpr int NP = SBL_BK / RPP;
-    struct State {
-        int c, kr;
-    };
-    struct Regs {
-        float4 v[NP];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.c = r0 + (tid % TPR) * 4;
-        s.kr = tid / TPR;
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int k = k0 + s.kr + ps * RPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend) {
-                const int kl = ALIGNED ? k0 : k;      // k0 is uniform: the lookup below then runs on the scalar unit
-                int sg = 0;
-#pragma unroll
-                for (int t = 1; t < SBL_MAX_KSEG; ++t)
-                    if (t < nseg && kl >= kcum[t]) sg = t;
-                const float* q = p[sg] + (long)(k - kcum[sg]) * ld + s.c;
-                if (s.c + 3 < rows) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    if (s.c + 0 < rows) v.x = q[0];
-                    if (s.c + 1 < rows) v.y = q[1];
-                    if (s.c + 2 < rows) v.z = q[2];
-                    if (s.c + 3 < rows) v.w = q[3];
-                }
-            }
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs& r, float4& cs) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            cs.x += r.v[ps].x; cs.y += r.v[ps].y; cs.z += r.v[ps].z; cs.w += r.v[ps].w;
-        }
-    }
-    __device__ __forceinline__ int col(const State& s) const { return s.c; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
-    }
-};
-
-// NHWC convolution geometry (one struct for fwd / dgrad / wgrad gathers).
-//   "out" grid (OH,OW) indexes GEMM rows; "src" tensor (SH,SW,C) is what gets gathered.
-//   fwd / wgrad:  src = x (H,W,Cin),  out = y grid (Ho,Wo):   ih = oh*stride - pad + kh
-//   dgrad:        src = dy (Ho,Wo,Cout), out = x grid (H,W):  t = oh + pad - kh, valid iff t%stride==0,
-//                                                              ih = t/stride < SH
-struct ConvGeom {
-    int NIMG, OH, OW;   // GEMM-row grid
-    int SH, SW, C;      // gathered tensor (NHWC)
-    int KH, KW, stride, pad;
-    // stride-2 input-gradient parity classes (cls != 0): the GEMM rows are the input pixels (2a + ph, 2b + pw) only,
-    // OH/OW are that sub-grid's dims, and GEMM-k runs over the ntaps <= 4 taps (tkh[t], tkw[t]) that can reach
-    // such a pixel (kh = ph + pad mod 2, kw likewise) instead of over all KH*KW taps, 3/4 of which would gather zeros.
-    int cls, ph, pw, ntaps;
-    int tkh[4], tkw[4];
-};
-
-template <bool DGRAD>
-__device__ __forceinline__ bool conv_src_coord(const ConvGeom& g, int oh, int ow, int kh, int kw, int& ih, int& iw) {
-    if (!DGRAD) {
-        ih = oh * g.stride - g.pad + kh;
-        iw = ow * g.stride - g.pad + kw;
-        return (unsigned)ih < (unsigned)g.SH && (unsigned)iw < (unsigned)g.SW;
-    } else {
-        if (g.cls) {
-            oh = 2 * oh + g.ph;
-            ow = 2 * ow + g.pw;
-        }
-        int th = oh + g.pad - kh, tw = ow + g.pad - kw;
-        if (th < 0 || tw < 0) return false;
-        if (g.stride == 2) {
-            if ((th | tw) & 1) return false;
-            ih = th >> 1;
-            iw = tw >> 1;
-        } else {
-            ih = th;
-            iw = tw;
-        }
-        return ih < g.SH && iw < g.SW;
-    }
-}
-
-// im2col rows, k-contiguous: row = output pixel, k = (kh,kw,c) with c fastest.  C % 16 == 0
-// so one BK slice never straddles a tap and each lane's float4 stays inside one pixel.
-template <int BR, bool DGRAD>
-struct ConvGatherKC {
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    ConvGeom g;
-    int rows;   // NIMG*OH*OW
-    struct State {
-        int img[BR / 64], oh[BR / 64], ow[BR / 64];
-        bool ok[BR / 64];
-        int kq;
-    };
-    struct Regs {
-        float4 v[BR / 64];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.kq = (tid & 3) * 4;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            int r = r0 + ps * 64 + (tid >> 2);
-            s.ok[ps] = r < rows;
-            if (!s.ok[ps]) r = 0;
-            int hw = g.OH * g.OW;
-            s.img[ps] = r / hw;
-            int rem = r - s.img[ps] * hw;
-            s.oh[ps] = rem / g.OW;
-            s.ow[ps] = rem - s.oh[ps] * g.OW;
-        }
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-        const int tap = k0 / g.C;          // block-uniform
-        const int c = k0 - tap * g.C + s.kq;
-        int kh = tap / g.KW, kw = tap - kh * g.KW;
-        if (DGRAD && g.cls) {
-            kh = g.tkh[0]; kw = g.tkw[0];
-#pragma unroll
-            for (int t = 1; t < 4; ++t)
-                if (t == tap) { kh = g.tkh[t]; kw = g.tkw[t]; }
-        }
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int ih, iw;
-            if (s.ok[ps] && k0 < kend && conv_src_coord<DGRAD>(g, s.oh[ps], s.ow[ps], kh, kw, ih, iw))
-                v = *reinterpret_cast<const float4*>(p + (((long)s.img[ps] * g.SH + ih) * g.SW + iw) * g.C + c);
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            const int row = ps * 64 + (tid >> 2);
-            lds[s.kq + 0][row] = r.v[ps].x;
-            lds[s.kq + 1][row] = r.v[ps].y;
-            lds[s.kq + 2][row] = r.v[ps].z;
-            lds[s.kq + 3][row] = r.v[ps].w;
-        }
-    }
-};
-
-// im2col columns, m-contiguous (weight gradient B operand): GEMM-k = output pixel,
-// GEMM-row r = (kh,kw,c) with c fastest; a lane's 4 consecutive r share one tap (C % 4 == 0).
-template <int BR>
-struct ConvGatherMC {
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    ConvGeom g;
-    int rows;   // KH*KW*C
-    static constexpr int TPR = BR / 4;
-    static constexpr int RPP = 256 / TPR;
-    static constexpr int NP = SBL_BK / RPP;
-    struct State {
-        int c, kh, kw, kr;
-        bool ok;
-    };
-    struct Regs {
-        float4 v[NP];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        int r = r0 + (tid % TPR) * 4;
-        s.ok = r < rows;
-        if (!s.ok) r = 0;
-        int tap = r / g.C;
-        s.c = r - tap * g.C;
-        s.kh = tap / g.KW;
-        s.kw = tap - s.kh * g.KW;
-        s.kr = tid / TPR;
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-        const int hw = g.OH * g.OW;
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int k = k0 + s.kr + ps * RPP;   // output pixel index
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s.ok && k < kend) {
-                int img = k / hw;
-                int rem = k - img * hw;
-                int oh = rem / g.OW, ow = rem - oh * g.OW;
-                int ih, iw;
-                if (conv_src_coord<false>(g, oh, ow, s.kh, s.kw, ih, iw))
-                    v = *reinterpret_cast<const float4*>(p + (((long)img * g.SH + ih) * g.SW + iw) * g.C + s.c);
-            }
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
-    }
-};
-
-// ---- position-major 3x3 / stride-1 convolutions on small maps (ResNet layers 3 and 4: 6x6 and 3x3 pixels).
-// With pad 1 a border pixel sees only 4 or 6 of the 9 taps; on a 3x3 map 40 % (6x6: 21 %) of the im2col matrix is
-// zero padding.  Ordering the GEMM rows position-major (row = pos * NIMG + img) makes the set of in-bounds taps
-// (nearly) uniform per tile, so each workgroup contracts only over the taps its positions can reach; products with
-// the padded zeros are skipped, every kept product is the same as before (bit-identical accumulation order per tap).
-template <int BR, bool DGRAD>
-struct ConvGatherPM {
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = true;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    ConvGeom g;
-    int rows;   // NIMG*OH*OW
-    unsigned long long taps;   // the workgroup's tap list, 4 bits each (set by sbl_conv_pm_kernel)
-    struct State {
-        int img[BR / 64], oh[BR / 64], ow[BR / 64];
-        bool ok[BR / 64];
-        int kq;
-    };
-    struct Regs {
-        float4 v[BR / 64];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.kq = (tid & 3) * 4;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            int r = r0 + ps * 64 + (tid >> 2);
-            s.ok[ps] = r < rows;
-            if (!s.ok[ps]) r = 0;
-            const int pos = r / g.NIMG;
-            s.img[ps] = r - pos * g.NIMG;
-            s.oh[ps] = pos / g.OW;
-            s.ow[ps] = pos - s.oh[ps] * g.OW;
-        }
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-        const int t = k0 / g.C;            // block-uniform
-        const int tap = (int)((taps >> (4 * t)) & 15ull);
-        const int c = k0 - t * g.C + s.kq;
-        const int kh = tap / g.KW, kw = tap - kh * g.KW;
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int ih, iw;
-            if (s.ok[ps] && k0 < kend && conv_src_coord<DGRAD>(g, s.oh[ps], s.ow[ps], kh, kw, ih, iw))
-                v = *reinterpret_cast<const float4*>(p + (((long)s.img[ps] * g.SH + ih) * g.SW + iw) * g.C + c);
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < BR / 64; ++ps) {
-            const int row = ps * 64 + (tid >> 2);
-            lds[s.kq + 0][row] = r.v[ps].x;
-            lds[s.kq + 1][row] = r.v[ps].y;
-            lds[s.kq + 2][row] = r.v[ps].z;
-            lds[s.kq + 3][row] = r.v[ps].w;
-        }
-    }
-};
-
-// Weight gradient, position-major: a tile of the (tap, ci) axis that lies inside ONE tap contracts only over the
-// output pixels for which that tap is in bounds - a rectangle [oh_lo, oh_lo+nh) x [ow_lo, ow_lo+nw) of the map, all
-// images: GEMM-k' = vp * NIMG + img with vp the index inside the rectangle.  PmRect is set per workgroup.
-struct PmRect {
-    int oh_lo, ow_lo, nw, dh, dw;    // source pixel = (oh + dh, ow + dw), always in bounds inside the rectangle
-};
-template <int BR>
-struct DenseMCPM {            // dY^T: element (co, k') = dy[pixel(k')][co]
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    long ld;
-    int rows;
-    int NIMG, OH, OW;
-    PmRect rc;
-    static constexpr int TPR = BR / 4;
-    static constexpr int RPP = 256 / TPR;
-    static constexpr int NP = SBL_BK / RPP;
-    struct State {
-        int c, kr;
-    };
-    struct Regs {
-        float4 v[NP];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        s.c = r0 + (tid % TPR) * 4;
-        s.kr = tid / TPR;
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int k = k0 + s.kr + ps * RPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend && s.c < rows) {
-                const int vp = k / NIMG, img = k - vp * NIMG;
-                const int a = vp / rc.nw, b = vp - a * rc.nw;
-                v = *reinterpret_cast<const float4*>(p + (((long)img * OH + rc.oh_lo + a) * OW + rc.ow_lo + b) * ld + s.c);
-            }
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State& s) const { return s.c; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
-    }
-};
-template <int BR>
-struct ConvGatherMCPM {       // x gathered: element ((tap, ci), k') = x[img, oh + dh, ow + dw, ci]
-    static constexpr bool kColSum = false;
-    static constexpr bool kKC = false;     // LDS image kind of the bf16 engine (bf16_tile.h)
-    const float* p;
-    ConvGeom g;
-    int rows;   // KH*KW*C
-    PmRect rc;
-    static constexpr int TPR = BR / 4;
-    static constexpr int RPP = 256 / TPR;
-    static constexpr int NP = SBL_BK / RPP;
-    struct State {
-        int c, kr;
-        bool ok;
-    };
-    struct Regs {
-        float4 v[NP];
-    };
-    __device__ __forceinline__ void init(State& s, int r0, int tid) const {
-        int r = r0 + (tid % TPR) * 4;
-        s.ok = r < rows;
-        if (!s.ok) r = 0;
-        s.c = r % g.C;
-        s.kr = tid / TPR;
-    }
-    __device__ __forceinline__ void load(const State& s, int k0, int kend, Regs& r) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int k = k0 + s.kr + ps * RPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s.ok && k < kend) {
-                const int vp = k / g.NIMG, img = k - vp * g.NIMG;
-                const int a = vp / rc.nw, b = vp - a * rc.nw;
-                v = *reinterpret_cast<const float4*>(p + (((long)img * g.SH + rc.oh_lo + a + rc.dh) * g.SW + rc.ow_lo + b + rc.dw) * g.C + s.c);
-            }
-            r.v[ps] = v;
-        }
-    }
-    __device__ __forceinline__ void accum(const Regs&, float4&) const {}
-    __device__ __forceinline__ int col(const State&) const { return 0; }
-    __device__ __forceinline__ void store(float (*lds)[BR + 4], const State& s, const Regs& r, int tid) const {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-            *reinterpret_cast<float4*>(&lds[s.kr + ps * RPP][(tid % TPR) * 4]) = r.v[ps];
-    }
-};
+#include "tile_loaders.h"
 
 // ------------------------------------------------------------------ epilogues
 // MODE 0: C = acc (+bias) (ReLU)   MODE 1: C += acc (non-atomic; one block per tile)
@@ -1007,13 +399,7 @@ static inline void sbl_launch_gemm2(const AL& al, const BL& bl, const EPI& epi, 
 template <bool DGRAD>
 __device__ __forceinline__ unsigned sbl_pm_tap_mask(const ConvGeom& g, int pos) {
     const int oh = pos / g.OW, ow = pos - oh * g.OW;
-    unsigned m = 0;
-    for (int kh = 0; kh < g.KH; ++kh)
-        for (int kw = 0; kw < g.KW; ++kw) {
-            int ih, iw;
-            if (conv_src_coord<DGRAD>(g, oh, ow, kh, kw, ih, iw)) m |= 1u << (kh * g.KW + kw);
-        }
-    return m;
+    return conv_tap_mask<DGRAD, false>(g, oh, ow, g.KH * g.KW);
 }
 // (Measured and not kept: a persistent grid drawing tiles from an atomic counter to balance the 4 / 6 / 9-tap tiles.
 // With only 1-2 tiles per resident workgroup the per-slot quantisation costs more than the balance gains: layer 3
@@ -1056,6 +442,7 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EP
     rc.ow_lo = max(0, -rc.dw);
     const int nh = min(g.OH, g.SH - rc.dh) - rc.oh_lo;
     rc.nw = min(g.OW, g.SW - rc.dw) - rc.ow_lo;
+    rc.rnw = 1.0f / (float)rc.nw;
     const int K = nh * rc.nw * g.NIMG;
     const int per = (K + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kchunk = (per + SBL_BK - 1) / SBL_BK * SBL_BK;

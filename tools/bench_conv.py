@@ -1,4 +1,4 @@
-"""time / profile the trunk convolutions at full size (NIMG = 32*29 = 928):  bench_conv.py [reps]"""
+"""time / profile the trunk convolutions at full size (NIMG = 32*29 = 928):  bench_conv.py [reps] [layer] [precisions, comma separated]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,6 +6,7 @@ from sbl_for_multilingual_lip_reading_amd import ops
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 only = sys.argv[2] if len(sys.argv) > 2 else ""
+precs = (sys.argv[3] if len(sys.argv) > 3 else "f32").split(",")
 NIMG = 928
 def timeit(fn, n=reps):
     for _ in range(2): fn()
@@ -17,7 +18,7 @@ def timeit(fn, n=reps):
     return a.elapsed_time(b) / n * 1e3
 for name, H, Cin, Cout, k, stride in [("layer1", 22, 64, 64, 3, 1), ("layer2", 11, 128, 128, 3, 1), ("layer3", 6, 256, 256, 3, 1), ("layer4", 3, 512, 512, 3, 1),
                                       ("l2.0.c1", 22, 64, 128, 3, 2), ("l3.0.c1", 11, 128, 256, 3, 2), ("l4.0.c1", 6, 256, 512, 3, 2)]:
-    if only and only != name: continue
+    if only not in ('', 'all') and only != name: continue
     pad = 1
     Ho = (H + 2 * pad - k) // stride + 1
     x = torch.randn(NIMG, H, H, Cin, device=dev); w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
@@ -27,7 +28,9 @@ for name, H, Cin, Cout, k, stride in [("layer1", 22, 64, 64, 3, 1), ("layer2", 1
     sp = None if os.environ.get("NOSTATS") else stats.data_ptr()
     dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty(Cout, k, k, Cin, device=dev)
     fl = 2.0 * NIMG * Ho * Ho * Cout * Cin * k * k / 1e6
-    t1 = timeit(lambda: ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), sp, NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
-    t2 = timeit(lambda: ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
-    t3 = timeit(lambda: ops.call("sbl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._s()))
-    print("%-8s %5.1f GF  fwd %7.1f us (%5.1f TF)  dgrad %7.1f us (%5.1f TF)  wgrad %7.1f us (%5.1f TF)" % (name, fl / 1e3, t1, fl / t1, t2, fl / t2, t3, fl / t3), flush=True)
+    for prec in precs:
+        ops.set_matmul_precision(prec)
+        t1 = timeit(lambda: ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), sp, NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
+        t2 = timeit(lambda: ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
+        t3 = timeit(lambda: ops.call("sbl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._s()))
+        print("%-8s %-6s %5.1f GF  fwd %7.1f us (%5.1f TF)  dgrad %7.1f us (%5.1f TF)  wgrad %7.1f us (%5.1f TF)" % (name, prec, fl / 1e3, t1, fl / t1, t2, fl / t2, t3, fl / t3), flush=True)
