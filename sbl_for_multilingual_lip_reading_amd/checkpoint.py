@@ -15,6 +15,18 @@ nothing is ever unpickled:
 import torch
 
 
+def _to_cpu(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().cpu().clone()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_to_cpu(v) for v in obj]
+    if obj is None or isinstance(obj, (int, float, str, bool)):
+        return obj
+    raise TypeError("optimizer state holds a %s: only tensors, numbers, strings and containers of them are saved" % type(obj).__name__)
+
+
 def save_checkpoint(path, model, optimizer=None, **meta):
     """model: Transformer (or any module of this package).  optimizer: TransformerOptimizer / FusedAdam / None."""
     m = model.module if hasattr(model, "module") else model          # nn.DataParallel wrapper, SBL/train.py:246-250
@@ -22,9 +34,10 @@ def save_checkpoint(path, model, optimizer=None, **meta):
     if optimizer is not None:
         inner = getattr(optimizer, "optimizer", optimizer)
         out["step_num"] = int(getattr(optimizer, "step_num", 0))
-        sd = inner.state_dict()
-        flat_state = all(not isinstance(v, dict) for v in sd.values())      # FusedAdam: plain tensors and scalars
-        out["optimizer_state"] = {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in sd.items()} if flat_state else None
+        # FusedAdam: flat tensors and scalars; torch.optim.Adam (the reference's optimizer, SBL/train.py:75): nested
+        # {'state': {idx: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} - plain containers of tensors and
+        # numbers either way, which torch.load(weights_only=True) reads back
+        out["optimizer_state"] = _to_cpu(inner.state_dict())
     for k, v in meta.items():
         if not isinstance(v, (int, float, str, bool)):
             raise TypeError("checkpoint metadata must be plain scalars/strings (got %s for %r)" % (type(v).__name__, k))

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
 }
 
 static bool at_small_ok(const SegDesc& d, int Lk_fixed, int mask_kind) {
-    static const int enabled = getenv("SBL_ATT_SMALL") ? atoi(getenv("SBL_ATT_SMALL")) : 1;   // A/B knob
+    constexpr int enabled = 1;
     if (!enabled || mask_kind == 2 || Lk_fixed > 32) return false;
     for (int s = 0; s < d.nseg; ++s)
         if (d.L[s] > 16) return false;
@@ -704,7 +704,7 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
     if (at_small_ok(d, Lk_fixed, 0) && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && sbl_aligned16(dq) && sbl_aligned16(dk) &&
         sbl_aligned16(dv)) {
         const int nprob = nseg * B * H;
-        static const int shared_kv = getenv("SBL_ATT_SHARED_KV") ? atoi(getenv("SBL_ATT_SHARED_KV")) : 1;   // A/B knob
+        constexpr int shared_kv = 1;
         if (Lk_fixed > 0 && nseg > 1 && !(shared_kv && nseg <= 8)) {      // atomics path accumulates: start from zero
             SBL_HIP(hipMemset2DAsync(dk, lddk * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
             SBL_HIP(hipMemset2DAsync(dv, lddv * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));

@@ -18,16 +18,15 @@ static inline int out_dim(int H, int K, int stride, int pad) { return (H + 2 * p
 
 // Position-major path for 3x3 / stride-1 convolutions on small maps (ResNet layers 2-4: 11x11, 6x6, 3x3): SBL_CONV_PM_HW =
 // largest Ho*Wo that takes it (0 = off; A/B knob; the 22x22 maps of layer 1 lose: 6 % padding, 434 vs 396 us)
-static const int g_pm_hw = getenv("SBL_CONV_PM_HW") ? atoi(getenv("SBL_CONV_PM_HW")) : 121;
+constexpr int g_pm_hw = 121;
 // forward / input-gradient tile of that path: 1 = 128x128, 2 = 128x64, 3 = 64x64, 0 = the ordinary launches' rule.  The
 // tiles are uneven (4 / 6 / 9 taps) and co-resident, so small tiles balance best: layer 4 forward 400 -> 307 us
 // (128 TF of algorithmic FLOPs), input gradient 431 -> 324 us; layer 2 352 -> 327 us
-static const int g_pm_tile = getenv("SBL_CONV_PM_TILE") ? atoi(getenv("SBL_CONV_PM_TILE")) : 3;
+constexpr int g_pm_tile = 3;
 static inline bool conv_pm_ok(int Ho, int Wo, int KH, int stride) { return KH == 3 && stride == 1 && Ho * Wo <= g_pm_hw; }
 
 #define SBL_CONV_WS_COUNTERS 4096      // same workspace convention as sbl_gemm_f32: int counters, then fp32 slabs
-static const int g_tailsplit = getenv("SBL_CONV_TAILSPLIT") ? atoi(getenv("SBL_CONV_TAILSPLIT")) : 1;   // A/B knob
-
+constexpr int g_tailsplit = 1;
 extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* stats, int NIMG, int H, int W, int Cin,
                               int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -89,7 +88,7 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     // all tiles are co-resident (<= 4 workgroups per CU), so the launch lasts as long as the fullest CU: pick the
     // largest tile whose count per CU (256 CUs) does not round up by more than ~20 % (522 128x128 tiles = 2.04/CU
     // would run at 3/CU speed; 1044 128x64 tiles = 4.08/CU at 5/CU)
-    static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
+    constexpr int q128 = 1;
     const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
     // (a 256x64 tile with 4x1 wavefronts of 64x64 was measured slower than 128x64 on the 64-channel layer: 442 vs 405 us)
     if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_FWD(128, 128, 2);
@@ -204,7 +203,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
             }                                                                                                 \
         }                                                                                                     \
     } while (0)
-    static const int q128 = getenv("SBL_CONV_Q128") ? atoi(getenv("SBL_CONV_Q128")) : 1;
+    constexpr int q128 = 1;
     const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
     if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_DG(128, 128, 2);
     else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG(128, 64, 2);
@@ -241,8 +240,8 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     // otherwise, and 6 / 12 workgroups per CU so that the uneven last chunks and the atomic epilogues of one
     // workgroup hide behind the others (measured, tools/bench_conv.py: 465/477/511/515 us -> 411/355/437/453 us for
     // layers 1-4); chunks stay >= 256 pixels
-    static const int wg_tile = getenv("SBL_WGRAD_TILE") ? atoi(getenv("SBL_WGRAD_TILE")) : 0;     // A/B knobs
-    static const int wg_target_env = getenv("SBL_WGRAD_TARGET") ? atoi(getenv("SBL_WGRAD_TARGET")) : 0;
+    constexpr int wg_tile = 0;
+    constexpr int wg_target_env = 0;
     const bool big = wg_tile ? wg_tile == 128 : (M >= 128 && N >= 1152);
     const int wg_target = wg_target_env ? wg_target_env : (big ? 1536 : 3072);
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_WGRAD)};
@@ -257,7 +256,7 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
         EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
         sbl_launch_gemm<DenseMC<BM, true>, ConvGatherMC<BN>, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s, sc); \
     } while (0)
-    static const int pm_wg_tile = getenv("SBL_PM_WG_TILE") ? atoi(getenv("SBL_PM_WG_TILE")) : 128;   // A/B knob
+    constexpr int pm_wg_tile = 128;
     if (conv_pm_ok(Ho, Wo, KH, stride) && big && M >= 128 && Cin % 128 == 0) {
         // one tap per tile of the (tap, ci) axis: contract only over the pixels that tap can reach
 #define SBL_KPMW_(P) sbl_conv_pm_wgrad_kernel<DenseMCPM<T_>, ConvGatherMCPM<T_>, EpiStore<2, false>, T_, T_, P>

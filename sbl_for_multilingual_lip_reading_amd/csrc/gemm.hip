@@ -117,13 +117,13 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
                 "sbl_gemm_f32: operand spans more than 2 GiB (buffer descriptor range)");
     const bool plain = !bias && !relu && !relu_mask;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 4096;   // tuning knob (4352x2048x512: 128x128 tiles 131 us, 64x64 115 us)
+    constexpr int big_min = 4096;   // tuning knob (4352x2048x512: 128x128 tiles 131 us, 64x64 115 us)
     const bool big = (M >= 1024 && N >= 256 && tiles64 >= big_min);
     // split K when the output has too few 64x64 tiles to fill 256 CUs: aim at ~256 workgroups, chunks of at
     // least one 64-deep macro step, at most 8 slices (the last-arriving workgroup reads every slab)
     int splits = 1;
-    static const int split_tiles = getenv("SBL_SPLIT_TILES") ? atoi(getenv("SBL_SPLIT_TILES")) : 192;   // tuning knobs
-    static const int split_target = getenv("SBL_SPLIT_TARGET") ? atoi(getenv("SBL_SPLIT_TARGET")) : 256;
+    constexpr int split_tiles = 192;
+    constexpr int split_target = 256;
     if (!big && tiles64 < split_tiles && K >= 128) {
         splits = (int)((split_target + tiles64 - 1) / tiles64);
         if (splits > K / 64) splits = K / 64;
@@ -150,11 +150,11 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
         const bool al_ok = (!a_kc || (sbl_aligned16(A) && lda % 4 == 0)) && (!b_kc || (sbl_aligned16(B) && ldb % 4 == 0));
         const bool k_ok = (!a_kc && !b_kc) || (K % 8 == 0);
         const long tiles32 = (long)sbl_cdiv(M, 32) * sbl_cdiv(N, 32);
-        static const int max_m = getenv("SBL_SKINNY_MAX_M") ? atoi(getenv("SBL_SKINNY_MAX_M")) : 512;      // tuning knob
-        static const int max_t = getenv("SBL_SKINNY_MAX_TILES") ? atoi(getenv("SBL_SKINNY_MAX_TILES")) : 2048;
+        constexpr int max_m = 512;
+        constexpr int max_t = 2048;
         // ... and d_model x d_model products up to ~1500 rows, where the 64x64 tiling would need split-K slabs to
         // fill the chip (measured 1440x512x512: fwd 18.5 vs 21.4 us, dX 16.1 vs 23.1, dW 15.8 vs 28.3)
-        static const int sq_rows = getenv("SBL_SKINNY_SQ_ROWS") ? atoi(getenv("SBL_SKINNY_SQ_ROWS")) : 1536;
+        constexpr int sq_rows = 1536;
         const bool shape_ok = transA ? ((K <= max_m && tiles32 <= max_t) || ((long)M * N <= 512L * 512 && K <= sq_rows))
                                      : ((M <= max_m && tiles32 <= max_t) || ((long)N * K <= 512L * 512 && M <= sq_rows));
         if (shape_ok && al_ok && k_ok && !(transA && transB)) {
@@ -170,15 +170,15 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
 #define SBL_GO(VEC, BM, BN, KU) \
     launch_trans<VEC, BM, BN, KU>(transA, transB, A, lda, B, ldb, C, ldc, bias, relu, relu_mask, ldm, mode, M, N, K, splits, sc, s)
     if (big) {
-        static const int big_ku = getenv("SBL_BIG_KU") ? atoi(getenv("SBL_BIG_KU")) : 1;      // tuning knob
+        constexpr int big_ku = 1;
         if (vec && big_ku == 2) SBL_GO(true, 128, 128, 2);
         else if (vec) SBL_GO(true, 128, 128, 1);
         else SBL_GO(false, 128, 128, 1);
     } else {
         // KU = 4 (69 KB of LDS, 2 workgroups per CU) while every workgroup of the launch is resident at once; beyond
         // 512 workgroups KU = 2 (35 KB, 4 per CU) keeps them all resident instead of running a second, part-filled
-        // round (measured 1440x2048x512: 36.6 vs 46.9 us; tools/sweep_gemm.sh)
-        static const int ku_env = getenv("SBL_TILED_KU") ? atoi(getenv("SBL_TILED_KU")) : 0;      // tuning knob
+        // round (measured 1440x2048x512: 36.6 vs 46.9 us)
+        constexpr int ku_env = 0;
         const int ku = ku_env ? ku_env : (tiles64 * splits > 512 ? 2 : 4);
         if (!vec) SBL_GO(false, 64, 64, 1);
         else if (ku == 1) SBL_GO(true, 64, 64, 1);
@@ -205,7 +205,7 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     const bool vec = sbl_aligned16(A0) && sbl_aligned16(A1) && sbl_aligned16(B0) && sbl_aligned16(B1) && lda % 4 == 0 && ldb % 4 == 0 && K % 8 == 0;
     SBL_REQUIRE(sbl_fits_u32((long)M * lda) && sbl_fits_u32((long)N * ldb), "sbl_gemm2_f32: operand spans more than 2 GiB (buffer descriptor range)");
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    static const int big_min = getenv("SBL_BIG_MIN_TILES") ? atoi(getenv("SBL_BIG_MIN_TILES")) : 4096;
+    constexpr int big_min = 4096;
     const bool big = (M >= 1024 && N >= 256 && 2 * tiles64 >= big_min);
     if (!vec || big) {      // shapes the decoder forward does not produce: two plain launches
         if (int e = sbl_gemm_f32(0, 1, M, N, K, A0, lda, B0, ldb, C0, ldc, bias0, relu, nullptr, 0, 0, nullptr, ws, ws_bytes, stream)) return e;
@@ -213,10 +213,10 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     }
     {
         const long tiles32 = (long)sbl_cdiv(M, 32) * sbl_cdiv(N, 32);
-        // (two problems = twice the workgroups: the register-only kernel stops paying at half the rows; tools/ms.py sweep in the step)
-        static const int max_m = getenv("SBL_SKINNY_MAX_M2") ? atoi(getenv("SBL_SKINNY_MAX_M2")) : 128;
-        static const int max_t = getenv("SBL_SKINNY_MAX_TILES") ? atoi(getenv("SBL_SKINNY_MAX_TILES")) : 2048;
-        static const int sq_rows = getenv("SBL_SKINNY_SQ_ROWS2") ? atoi(getenv("SBL_SKINNY_SQ_ROWS2")) : 768;
+        // (two problems = twice the workgroups: the register-only kernel stops paying at half the rows; swept inside the step)
+        constexpr int max_m = 128;
+        constexpr int max_t = 2048;
+        constexpr int sq_rows = 768;
         if ((M <= max_m && tiles32 <= max_t) || ((long)N * K <= 512L * 512 && M <= sq_rows)) {
             SkinnyEpi e{C0, ldc, bias0, relu, nullptr, 0, 0, nullptr, sbl_next_stamp_slot(SBL_KID_SKINNY)};
             SkinnyDual du{A1, B1, C1, bias1};
@@ -226,8 +226,8 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
         }
     }
     int splits = 1;
-    static const int split_tiles = getenv("SBL_SPLIT_TILES") ? atoi(getenv("SBL_SPLIT_TILES")) : 192;
-    static const int split_target = getenv("SBL_SPLIT_TARGET") ? atoi(getenv("SBL_SPLIT_TARGET")) : 256;
+    constexpr int split_tiles = 192;
+    constexpr int split_target = 256;
     if (2 * tiles64 < split_tiles && K >= 128) {
         splits = (int)((split_target + 2 * tiles64 - 1) / (2 * tiles64));
         if (splits > K / 64) splits = K / 64;
@@ -249,7 +249,7 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     DenseKC<64, true> bl{B0, ldb, N};
     EpiStore<0, false> e{C0, ldc, bias0, relu, nullptr, nullptr, 0};
     GemmDual du{A1, B1, C1, bias1};
-    static const int ku_env = getenv("SBL_TILED_KU") ? atoi(getenv("SBL_TILED_KU")) : 0;
+    constexpr int ku_env = 0;
     const int ku = ku_env ? ku_env : (2 * tiles64 * splits > 512 ? 2 : 4);
     if (ku == 2) sbl_launch_gemm2<DenseKC<64, true>, DenseKC<64, true>, EpiStore<0, false>, 64, 64, 2>(al, bl, e, du, M, N, K, splits, s, sc);
     else sbl_launch_gemm2<DenseKC<64, true>, DenseKC<64, true>, EpiStore<0, false>, 64, 64, 4>(al, bl, e, du, M, N, K, splits, s, sc);
@@ -266,9 +266,9 @@ extern "C" int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda,
     hipStream_t s = (hipStream_t)stream;
     SBL_REQUIRE(nseg >= 1 && nseg <= SBL_MAX_KSEG && A_ptrs && B_ptrs && seg_rows && C, "sbl_wgrad_seg_f32: bad segment list (nseg=%d)", nseg);
     SBL_REQUIRE(M > 0 && N > 0 && lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0, "sbl_wgrad_seg_f32: bad dims M=%d N=%d lda=%ld ldb=%ld", M, N, lda, ldb);
-    static const int seg_tile_env = getenv("SBL_SEG_TILE") ? atoi(getenv("SBL_SEG_TILE")) : 0;       // tuning knobs
-    static const int seg_ku = getenv("SBL_SEG_KU") ? atoi(getenv("SBL_SEG_KU")) : 2;
-    static const int seg_target = getenv("SBL_SEG_TARGET") ? atoi(getenv("SBL_SEG_TARGET")) : 768;
+    constexpr int seg_tile_env = 0;
+    constexpr int seg_ku = 2;
+    constexpr int seg_target = 768;
     long K = 0;
     bool aligned = true;
     for (int t = 0; t < nseg; ++t) {
@@ -302,7 +302,7 @@ extern "C" int sbl_wgrad_seg_f32(int nseg, const float* const* A_ptrs, long lda,
     };
     using std::integral_constant;
     // 128x128 tiles (twice the flops per staged byte) once the weight has enough of them to split K over; measured at
-    // K = 4352 rows: 2048x512 67 vs 52 TF, 1536x512 58 vs 50, 512x512 26 vs 34 (tools/bench_gemm2.py)
+    // K = 4352 rows: 2048x512 67 vs 52 TF, 1536x512 58 vs 50, 512x512 26 vs 34
     const int seg_tile = seg_tile_env ? seg_tile_env : ((long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128) >= 48 ? 128 : 64);
     if (!aligned) go(SegMC<64, false>{}, integral_constant<int, 64>{}, integral_constant<int, 2>{});
     else if (seg_tile == 128) go(SegMC<128, true>{}, integral_constant<int, 128>{}, integral_constant<int, 1>{});

@@ -305,8 +305,10 @@ __device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const 
                                               bool colsum_tile) {
     if constexpr (PREC == 0)
         sbl_gemm_tile_f32<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
-    else
-        sbl_gemm_tile_bf<AL, BL, EPI, BM, BN, KU, WN, PREC>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
+    else      // the bf16 bodies always stage one 16-deep slab per barrier: at 6 / 3 / 1 MFMAs per 32x32x16 block they are bound by
+              // operand conversion and load latency, which more resident workgroups (less LDS each) hide better than longer
+              // macro steps (4352x512x512 alone: 29 us at KU = 1 against 37 us at KU = 2)
+        sbl_gemm_tile_bf<AL, BL, EPI, BM, BN, 1, WN, PREC>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
 }
 
 // Matrix-product precision of the tile engine (sbl_set_matmul_precision): 0 = fp32 MFMA, 6 / 3 / 1 = bf16 MFMA terms.

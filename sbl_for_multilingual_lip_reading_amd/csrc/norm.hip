@@ -231,7 +231,7 @@ extern "C" int sbl_bn_bwd_reduce(const float* dy, const float* y, const float* x
     // ws = the stream's GEMM workspace (int counters, all zero between launches, then fp32 slabs): block partials go
     // to the slabs and the last-arriving block reduces them; without a workspace every block ends with 2*C double
     // atomics on the same addresses, which serialise (measured 4x slower on the 22x22x64 layer)
-    static const int max_blocks = getenv("SBL_BN_RED_BLOCKS") ? atoi(getenv("SBL_BN_RED_BLOCKS")) : 512;
+    constexpr int max_blocks = 512;
     const int rg = 256 / (C / 4);
     long blocks = (rows + 4L * rg - 1) / (4L * rg);                 // >= 4 rows per lane
     if (blocks > max_blocks) blocks = max_blocks;
@@ -500,7 +500,7 @@ extern "C" int sbl_add_layernorm_bwd(const float* dy, const float* x, const floa
     SBL_REQUIRE(sbl_aligned16(dy) && sbl_aligned16(x) && sbl_aligned16(dz) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma), "sbl_add_layernorm_bwd: unaligned");
     // few, fat workgroups: each ends with 1024 float atomics on the same dgamma/dbeta words
     // 16 rows per workgroup (4 waves x 4 rows in flight); each workgroup ends with 1024 float atomics
-    static const int ln_bwd_blocks = getenv("SBL_LN_BWD_BLOCKS") ? atoi(getenv("SBL_LN_BWD_BLOCKS")) : 128;   // tuning knob
+    constexpr int ln_bwd_blocks = 128;
     int blocks = sbl_cdiv(M, 16);
     if (blocks > ln_bwd_blocks) blocks = ln_bwd_blocks;
     const int rpb = sbl_cdiv(sbl_cdiv(M, blocks), 16) * 16;

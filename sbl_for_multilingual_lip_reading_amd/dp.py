@@ -4,9 +4,9 @@ exchange per step.
 The reference wraps the model in single-process nn.DataParallel (SBL/train.py:115): per step it re-broadcasts
 324 MB of parameters from GPU0 and reduce-adds 324 MB of gradients back to GPU0 (hub and spoke).  Here every rank
 keeps its replica; parameters and gradients live in two flat fp32 buffers, so the exchange is a handful of large
-RCCL all-reduces over xGMI (no per-tensor launches, no parameter broadcast), issued on a side stream per segment
-in reverse-autograd order (decoder -> encoder -> visual frontend) so the frontend's backward overlaps the
-decoder's all-reduce.  BatchNorm statistics stay per replica, like the reference (no SyncBN).
+RCCL all-reduces over xGMI (no per-tensor launches, no parameter broadcast), issued on a side stream in ~25 MB
+buckets in reverse-autograd order (decoder -> encoder -> ResNet stages 4..2 -> stage 1 + stem) so that all but the
+last 0.6 MB travels beside the remaining backward.  BatchNorm statistics stay per replica, like the reference (no SyncBN).
 """
 import torch
 import torch.distributed as dist
@@ -42,10 +42,13 @@ def _ordered_params(model):
 class FlatModel:
     """Re-points every parameter (and its .grad) of `model` at a slice of one flat fp32 buffer.
 
-    segments: name prefixes in the order their gradients complete during backward; each becomes one
-    contiguous range of the flat buffers = one all-reduce."""
+    SEGMENTS: name prefixes in the order their gradients complete during backward (reverse autograd order: decoder,
+    encoder, then the ResNet stages from the last to the first, the Conv3d stem at the very end); each becomes one
+    contiguous range of the flat buffers, all-reduced in buckets of <= GradientExchange.bucket_bytes as soon as backward
+    has passed it.  Only layer1 + stem (0.6 MB) are left to exchange after the step."""
 
-    SEGMENTS = ("decoder.", "encoder.", "visual_frontend.")
+    SEGMENTS = ("decoder.", "encoder.", "visual_frontend.resnet18.layer4.", "visual_frontend.resnet18.layer3.",
+                "visual_frontend.resnet18.layer2.", "visual_frontend.")
 
     def __init__(self, model):
         self.model = model
@@ -57,7 +60,6 @@ class FlatModel:
             seg = next((s for s in self.SEGMENTS if n.startswith(s)), self.SEGMENTS[-1])
             by_seg[seg].append(p)
         dev = params[0].device
-        total = sum(p.numel() for p in params)
         # 16-byte alignment of every tensor start (float4 loads in the kernels): pad numel to a multiple of 4
         pad = lambda n: (n + 3) // 4 * 4
         total = sum(pad(p.numel()) for p in params)
@@ -78,12 +80,33 @@ class FlatModel:
                     # ops.* backward kernels accumulate straight into this buffer (GEMM '+=' epilogues, atomics)
                     # and hand autograd None, so no AccumulateGrad add kernels run for these parameters
                     p._sbl_grad = p.grad
+                    p._sbl_flat = self
                     off += pad(n)
                 self.ranges[seg] = (start, off)
         self.numel = total
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def reattach(self):
+        """Repair after a foreign `zero_grad(set_to_none=True)` (torch.optim's default) or an assignment to `p.grad`: the
+        kernels accumulate into the flat gradient whatever `p.grad` says, so a parameter whose `.grad` was dropped gets
+        its slice zeroed (= the fresh gradient the caller asked for) and `.grad` pointed back at it; an assigned foreign
+        gradient is copied into the slice first.  Called by ops._gbuf from the first tape node of a backward that finds
+        a detached parameter, i.e. before any kernel of that backward has accumulated."""
+        dropped = [(p, off) for p, off, _ in self.slots if p.grad is None]
+        with torch.no_grad():
+            if len(dropped) == len(self.slots):
+                self.flat_grad.zero_()                       # the common case: one fill
+            else:
+                for p, off in dropped:
+                    self.flat_grad[off:off + p.numel()].zero_()
+            for p, off, _ in self.slots:
+                view = self.flat_grad[off:off + p.numel()].view(p.shape)
+                if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                p.grad = view
+                p._sbl_grad = view
 
     def trainable_ranges(self):
         """Maximal contiguous [a, b) ranges of the flat buffers whose parameters have requires_grad=True (the
@@ -102,6 +125,12 @@ class FlatModel:
         a, b = self.ranges[seg]
         return self.flat_grad[a:b]
 
+    def span(self, prefix):
+        """[lo, hi) of the flat buffers covering every segment whose name starts with `prefix` (segments are laid out in
+        SEGMENTS order, so e.g. "visual_frontend." spans the four frontend segments)."""
+        r = [self.ranges[s] for s in self.SEGMENTS if s.startswith(prefix)]
+        return min(a for a, _ in r), max(b for _, b in r)
+
 
 def _ops():
     from . import ops
@@ -109,27 +138,31 @@ def _ops():
 
 
 class GradientExchange:
-    """Averages the flat gradient over ranks: one RCCL all-reduce per segment on a side stream, launched from
-    a hook that fires when the first parameter of the NEXT segment receives its gradient (i.e. the previous
-    segment's backward is complete), overlapped with the remaining backward."""
+    """Averages (average=True) or sums the flat gradient over ranks with RCCL all-reduces on a side stream, one bucket
+    of <= bucket_bytes at a time in reverse-autograd order (~13 x 25 MB), each segment launched from a tensor
+    hook that fires when backward has passed it, so the exchange runs beside the remaining backward.  average=False pairs
+    with FusedAdam(grad_scale=1/world): the 1/R then costs nothing (folded into the update)."""
 
-    def __init__(self, flat: FlatModel, world_size: int, overlap: bool = True):
+    def __init__(self, flat: FlatModel, world_size: int, overlap: bool = True, average: bool = True,
+                 bucket_bytes: int = 25 << 20):
         self.flat = flat
         self.world = world_size
+        self.average = average
+        self.bucket = max(4, bucket_bytes // 4 // 4 * 4)          # elements per bucket, 16-byte aligned
         self.cuda = flat.flat_grad.is_cuda          # CPU tensors + gloo are used by the world_size-2 unit tests
         self.stream = torch.cuda.Stream() if (self.cuda and world_size > 1) else None
-        self._done = []
         self._hooks = []
         self._pending = []
+        self.launches = []          # (segment, elements) per all-reduce issued, for tests / the bench line
         if world_size > 1 and overlap:
             self._install()
 
     def _install(self):
-        """Backward reaches the gradient of the encoder output only after the whole decoder (all 16 steps and
-        the hoisted K/V projections) has been differentiated, and the gradient of the frontend features only
-        after the encoder: tensor hooks on those two activations launch the finished segment's all-reduce while
-        the rest of backward is still running.  (Parameter hooks cannot be used: the kernels accumulate into the
-        flat gradient buffer themselves and autograd never sees those gradients.)"""
+        """A segment's gradients are complete when backward reaches the gradient of the activation that FEEDS it: the
+        encoder output for the decoder (all 16 steps and the hoisted K/V projections are behind it), the frontend
+        features for the encoder, and the input of ResNet stage k for stage k.  Tensor hooks there launch the finished
+        segment while the rest of backward runs.  (Parameter hooks cannot be used: the kernels accumulate into the flat
+        gradient buffer themselves and autograd never sees those gradients.)"""
         model = self.flat.model
 
         def on_encoder_out(mod, inp, out):
@@ -141,8 +174,20 @@ class GradientExchange:
             if out.requires_grad:
                 out.register_hook(lambda g: self.launch("encoder."))
 
+        def stage_pre_hook(seg):
+            def pre(mod, inp):
+                x = inp[0]
+                if torch.is_tensor(x) and x.requires_grad:
+                    x.register_hook(lambda g: self.launch(seg))
+            return pre
+
         self._hooks.append(model.encoder.register_forward_hook(on_encoder_out))
         self._hooks.append(model.visual_frontend.register_forward_hook(on_frontend_out))
+        res = getattr(model.visual_frontend, "resnet18", None)
+        if res is not None:
+            for k in (4, 3, 2):
+                self._hooks.append(getattr(res, "layer%d" % k).register_forward_pre_hook(
+                    stage_pre_hook("visual_frontend.resnet18.layer%d." % k)))
 
     def close(self):
         """Remove the forward hooks (the exchange then only runs when launch() / finish() are called explicitly)."""
@@ -150,10 +195,21 @@ class GradientExchange:
             h.remove()
         self._hooks = []
 
+    def _all_reduce(self, seg, g):
+        for a in range(0, g.numel(), self.bucket):
+            b = g[a:a + self.bucket]
+            if self.average:
+                b.mul_(1.0 / self.world)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            self.launches.append((seg, b.numel()))
+
     def launch(self, seg):
-        if self.world <= 1:
+        if self.world <= 1 or seg in self._pending:
             return
         g = self.flat.segment_grad(seg)
+        self._pending.append(seg)
+        if g.numel() == 0:
+            return
         if self.cuda:
             cur = torch.cuda.current_stream()
             # the finished segment's merged weight-gradient GEMMs (decoder and encoder layers defer theirs) must be
@@ -161,23 +217,19 @@ class GradientExchange:
             _ops().flush_deferred()
             side = _ops()._side_streams.get(cur.device_index)
             if side is not None:
-                self.stream.wait_stream(side)
+                self.stream.wait_stream(side)       # trunk / deferred weight gradients are accumulated there
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
-                g.mul_(1.0 / self.world)
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                self._all_reduce(seg, g)
         else:
-            g.mul_(1.0 / self.world)
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        self._pending.append(seg)
+            self._all_reduce(seg, g)
 
     def finish(self):
-        """Call after backward: exchanges the last segment and joins the side stream."""
+        """Call after backward: exchanges whatever has not gone out yet (layer1 + stem) and joins the side stream."""
         if self.world <= 1:
             return
         for seg in FlatModel.SEGMENTS:
-            if seg not in self._pending:
-                self.launch(seg)
+            self.launch(seg)
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending = []

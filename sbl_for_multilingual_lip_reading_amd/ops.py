@@ -9,8 +9,6 @@ non-zero status raises.
 All Functions are hipGraph-capturable: no host sync, no host read of device data;
 dropout seeds and teacher-forcing coins live in device memory.
 """
-import os
-
 import torch
 
 try:
@@ -65,7 +63,14 @@ class DropoutState:
     stream offset per dropout site per forward; `bump()` advances the seed on the
     device (one tiny kernel), so a captured graph draws new masks on every replay."""
 
-    def __init__(self, device, seed=0x5B1C0FFEE):
+    def __init__(self, device, seed=None):
+        if seed is None:
+            # data-parallel replicas draw independent masks (nn.DataParallel's replicas each use their device's
+            # generator, SBL/train.py:115): fold the rank into the default seed
+            seed = 0x5B1C0FFEE
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                seed ^= (dist.get_rank() * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
         self.seed = torch.tensor([seed], dtype=torch.int64, device=device)
         self._offset = 0
 
@@ -134,19 +139,11 @@ def _xs_out(*ts):
                     t.record_stream(main)
 
 
-CONV_WGRAD_SIDE = os.environ.get("SBL_CONV_WGRAD_SIDE", "1") != "0"
-# the second stream also carries the merged decoder weight-gradient GEMMs during the frontend backward; only every
-# k-th trunk dW goes there so that neither stream becomes the longer one
-CONV_WGRAD_SIDE_EVERY = int(os.environ.get("SBL_CONV_WGRAD_SIDE_EVERY", "1"))
-# the decoder's grouped weight-gradient launch joins at the end of backward, not right after it is issued (A/B knob)
-WGRAD_JOIN_AT_END = os.environ.get("SBL_WGRAD_JOIN_AT_END", "1") != "0"
-# bn1's backward reduction in the epilogue of conv2's input-gradient convolution (A/B knob)
-FUSE_BN_REDUCE = os.environ.get("SBL_FUSE_BN_REDUCE", "1") != "0"
 _side_join_state = {}      # per device: nn.DataParallel drives one replica per device from its own thread
 
 
 def _side_join_for_current_device():
-    return _side_join_state.setdefault(torch.cuda.current_device(), {"armed": False, "n": 0})
+    return _side_join_state.setdefault(torch.cuda.current_device(), {"armed": False})
 
 
 def _arm_side_join():
@@ -157,7 +154,6 @@ def _arm_side_join():
 
         def join():
             _side_join["armed"] = False
-            _side_join["n"] = 0
             cur = torch.cuda.current_stream()
             side = _side_streams.get(cur.device_index)
             if side is not None and side != cur:
@@ -173,24 +169,6 @@ def _side_to_main():
         main = _main_streams.get(cur.device_index)
         if main is not None:
             main.wait_stream(cur)
-
-
-_aux_streams = {}
-# Off by default: with the decoder's second stream also forking an auxiliary stream, hipStreamEndCapture /
-# instantiate segfaults on ROCm 7.2 (main+aux and main+side capture fine; main+side+aux does not), and
-# main+side (92.8 ms/step) beats main+aux (113 ms).  SBL_OFFLOAD_WGRAD=1 enables it for single-stream runs.
-OFFLOAD_WGRAD = os.environ.get("SBL_OFFLOAD_WGRAD", "0") == "1"
-
-
-def _aux_for(cur):
-    """Auxiliary stream paired with `cur`: weight-gradient GEMMs are not on backward's dependency chain (nothing
-    downstream reads dW before the step ends), so they are issued there and overlap the chain of small
-    dX / attention / LayerNorm kernels instead of lengthening it."""
-    key = (cur.device_index, cur.cuda_stream)
-    st = _aux_streams.get(key)
-    if st is None:
-        st = _aux_streams[key] = torch.cuda.Stream(device=cur.device_index)
-    return st
 
 
 class WgradCollector:
@@ -230,16 +208,16 @@ class WgradCollector:
         run = cur
         if side is not None and cur != side:
             cur.wait_stream(side)              # operands produced by the other direction's stream
-            if FLUSH_ON_SIDE:
-                side.wait_stream(cur)
-                run = side
+            side.wait_stream(cur)
+            run = side
         with torch.cuda.stream(run):
             # weights whose stages have the same row structure (all layer weights of both directions) form one group
             groups = {}
             for e in self.entries.values():
                 groups.setdefault(tuple(e["rows"]), []).append(e)
             for rows0, ents in groups.items():
-                grouped = GROUP_WGRAD and len(ents) > 1 and len(rows0) <= 16 and all(r % 16 == 0 for r in rows0)
+                grouped = (len(ents) > 1 and len(rows0) <= 16 and all(r % 16 == 0 for r in rows0)
+                           and all(e["M"] % 4 == 0 and e["N"] % 4 == 0 for e in ents))
                 if grouped:
                     # one launch for every weight: each 128x128 tile of each gradient is owned by one workgroup over
                     # the whole K = all stages' rows (no split-K, no atomics; see sbl_wgrad_group_f32)
@@ -285,9 +263,6 @@ class WgradCollector:
             lst.remove(self)
 
 
-FLUSH_ON_SIDE = os.environ.get("SBL_FLUSH_ON_SIDE", "1") != "0"
-GROUP_WGRAD = os.environ.get("SBL_GROUP_WGRAD", "1") != "0"
-FLUSH_AT_DECODER_END = os.environ.get("SBL_FLUSH_AT_DECODER_END", "1") == "1"
 _group_tables = {}
 _armed = {}       # device index -> collectors with pending entries
 
@@ -299,7 +274,6 @@ def flush_deferred():
         c.flush()
 
 
-DEFER_WGRAD = os.environ.get("SBL_DEFER_WGRAD", "1") != "0"
 import threading as _threading
 
 _tls = _threading.local()      # the collector of the forward pass running on THIS thread (nn.DataParallel: one per replica)
@@ -307,7 +281,7 @@ _tls = _threading.local()      # the collector of the forward pass running on TH
 
 def begin_defer():
     """Decoder forward: tape nodes created from here on defer their weight gradients (if enabled)."""
-    _tls.collector = WgradCollector() if DEFER_WGRAD else None
+    _tls.collector = WgradCollector()
 
 
 def end_defer():
@@ -316,36 +290,19 @@ def end_defer():
 
 def wgrad_gemm(M, N, K, A, lda, B, ldb, C, ldc, acc, colsum, defer=None):
     """dW (+)= A^T B with the bias gradient riding on it.  With a collector and a persistent gradient buffer (acc=1)
-    the product is deferred to one all-stages GEMM per weight; else it is issued now (optionally on the auxiliary
-    stream)."""
+    the product is deferred to one all-stages GEMM per weight; else it is issued now."""
     if defer is not None and acc:
         defer.add(C, ldc, colsum, A, lda, B, ldb, K, M, N)
         return
-    if not (acc and OFFLOAD_WGRAD):
-        gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, accumulate=acc, colsum=colsum)
-        return
-    cur = torch.cuda.current_stream()
-    aux = _aux_for(cur)
-    aux.wait_stream(cur)
-    with torch.cuda.stream(aux):
-        gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, accumulate=1, colsum=colsum)
-    A.record_stream(aux)
-    B.record_stream(aux)
+    gemm(1, 0, M, N, K, A, lda, B, ldb, C, ldc, accumulate=acc, colsum=colsum)
 
 
 def join_side_streams():
-    """Make the current stream wait for everything enqueued on the side / auxiliary streams (end of a step).
-    Each auxiliary stream is joined only into the stream it was forked from."""
+    """Make the current stream wait for everything enqueued on the side stream (end of a step)."""
     cur = torch.cuda.current_stream()
     side = _side_streams.get(cur.device_index)
     if side is not None:
-        a = _aux_streams.get((cur.device_index, side.cuda_stream))
-        if a is not None:
-            side.wait_stream(a)
         cur.wait_stream(side)
-    a = _aux_streams.get((cur.device_index, cur.cuda_stream))
-    if a is not None:
-        cur.wait_stream(a)
 
 
 # split-K workspace: int[4096] tile counters (kept zero by the kernel) + fp32 partial slabs, one per stream so
@@ -393,8 +350,18 @@ def _segs(segL):
 def _gbuf(p):
     """The persistent gradient buffer of a parameter, if the model was flattened (dp.FlatModel): backward then
     accumulates into it inside the kernels (GEMM epilogue '+=', atomics) and returns None to autograd, instead of
-    allocating a gradient and having AccumulateGrad add it with a separate kernel (16x per decoder parameter)."""
-    return None if p is None else getattr(p, "_sbl_grad", None)
+    allocating a gradient and having AccumulateGrad add it with a separate kernel (16x per decoder parameter).
+    If the caller dropped or replaced `p.grad` since (torch.optim's zero_grad(set_to_none=True) default), the flat model
+    re-attaches every parameter first (dp.FlatModel.reattach), so `p.grad` always IS the buffer the kernels write."""
+    if p is None:
+        return None
+    g = getattr(p, "_sbl_grad", None)
+    if g is None:
+        return None
+    if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+        p._sbl_flat.reattach()
+        g = p._sbl_grad
+    return g
 
 
 def _target(buf, shape, dev, zero=False):
@@ -754,9 +721,9 @@ class MHAFn(torch.autograd.Function):
         dy2 = dy.contiguous().view(M, D)
         # LayerNorm(dropout(o) + x) adjoint: dz = grad of the residual x, do = grad of the pre-dropout o
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
-        # a separate pre-dropout gradient buffer is also needed without dropout when the weight-gradient GEMM reads
-        # it from the auxiliary stream while this stream accumulates the input gradient into dz in place
-        sep = drop_p > 0 or ((OFFLOAD_WGRAD or ctx.defer is not None) and g_fc[0] is not None)
+        # a separate pre-dropout gradient buffer is also needed without dropout when the deferred weight-gradient GEMM
+        # reads it later while this stream accumulates the input gradient into dz in place
+        sep = drop_p > 0 or (ctx.defer is not None and g_fc[0] is not None)
         do = torch.empty(M, D, device=dev, dtype=torch.float32) if sep else None
         dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
         dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
@@ -840,9 +807,8 @@ class FFNFn(torch.autograd.Function):
         _xs_in(dy)
         dy2 = dy.contiguous().view(M, D)
         dz = torch.empty(M, D, device=dev, dtype=torch.float32)
-        # a separate pre-dropout gradient buffer is also needed without dropout when the weight-gradient GEMM reads
-        # it from the auxiliary stream while this stream accumulates the input gradient into dz in place
-        sep = drop_p > 0 or ((OFFLOAD_WGRAD or ctx.defer is not None) and g2[0] is not None)
+        # (same as in MHAFn.backward)
+        sep = drop_p > 0 or (ctx.defer is not None and g2[0] is not None)
         do = torch.empty(M, D, device=dev, dtype=torch.float32) if sep else None
         dgamma, _, dgamma_ret = _target(g_ln[0], (D,), dev, zero=True)
         dbeta, _, dbeta_ret = _target(g_ln[1], (D,), dev, zero=True)
@@ -1080,7 +1046,7 @@ class ConvBNFn(torch.autograd.Function):
         ctx.cfg = (relu, stride, pad, training, res is not None)
         ctx.gb_bn = (_gbuf(gamma), _gbuf(beta))
         ctx.box_out = ctx.box_in = None
-        if FUSE_BN_REDUCE and training:      # (grad mode is off inside Function.forward; backward only runs if a tape exists)
+        if training:      # (grad mode is off inside Function.forward; backward only runs if a tape exists)
             if box_out is not None and relu and res is None:
                 box_out.update(conv=conv, mean=mean, invstd=invstd, act=y)
                 ctx.box_out = box_out
@@ -1135,9 +1101,7 @@ class ConvBNFn(torch.autograd.Function):
                 call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                      _workspace().data_ptr(), WS_BYTES, _s())
         gw = _gbuf(w)
-        _side_join = _side_join_for_current_device()
-        _side_join["n"] += 1
-        if gw is not None and CONV_WGRAD_SIDE and (CONV_WGRAD_SIDE_EVERY <= 1 or _side_join["n"] % CONV_WGRAD_SIDE_EVERY == 0):
+        if gw is not None:
             # the weight gradient is off backward's dependency chain: with a persistent gradient buffer it is issued
             # on the second stream, where its workgroups fill the CUs that the chain's kernels (tile-count
             # quantisation: 522 workgroups on 256 CUs) leave idle; joined by an end-of-backward engine callback

@@ -172,13 +172,10 @@ class Decoder(nn.Module):
                         ops.argmax_select(None, golds[d], ys[d], k, 0)
 
         ops.begin_defer()      # decoder weights are used once per stage: their dW GEMMs are deferred and merged
-        if encoder_outputs.requires_grad and torch.is_grad_enabled() and ops.FLUSH_AT_DECODER_END:
+        if encoder_outputs.requires_grad and torch.is_grad_enabled():
             # d(loss)/d(encoder_outputs) is complete only after every decoder tape node has run: issue the merged
-            # weight-gradient GEMMs then (side stream).  The grouped launch fills the chip for ~5 ms and delays the
-            # encoder backward that follows on the main stream (its first GEMM waited 4.1 ms for CUs in one trace);
-            # flushing only when backward reaches the encoder INPUT instead (SBL_FLUSH_AT_DECODER_END=0, the Encoder's
-            # own hook) moves that time under the frontend backward - measured equal within noise (57.6 vs 57.9 ms):
-            # the chip is throughput-bound either way.
+            # weight-gradient GEMMs then (side stream), beside the encoder / frontend backward.  (Flushing when backward
+            # reaches the encoder INPUT instead measured equal within noise: the chip is throughput-bound either way.)
             encoder_outputs.register_hook(lambda g: ops.flush_deferred())
         for (i0, i1) in stages:
             segL = tuple(range(i0 + 1, i1 + 2))            # prefix lengths of the steps in this stage

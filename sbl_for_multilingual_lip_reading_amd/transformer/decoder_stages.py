@@ -401,7 +401,7 @@ def _flush_weight_grads(wg, rows_of, R, main, side):
     """C (+)= A^T B for every collected (C, ldc, colsum, A, lda, B, ldb, M, N); grouped launches (one per distinct row
     count) on the side stream when the rows are a multiple of 16, per-weight split-K GEMMs otherwise."""
     import ctypes as ct
-    run = side if (side is not None and ops.FLUSH_ON_SIDE) else main
+    run = side if side is not None else main
     if run is not main:
         run.wait_stream(main)
     groups = {}
@@ -409,7 +409,7 @@ def _flush_weight_grads(wg, rows_of, R, main, side):
         groups.setdefault(rows_of.get(id(e[0]), R), []).append(e)
     with torch.cuda.stream(run):
         for rows, ents in groups.items():
-            if ops.GROUP_WGRAD and rows % 16 == 0 and len(ents) > 1:
+            if rows % 16 == 0 and len(ents) > 1 and all(e[7] % 4 == 0 and e[8] % 4 == 0 for e in ents):
                 n = len(ents)
                 need = ops._lib.load().sbl_wgrad_group_table_bytes(n)
                 key = (run.device_index, run.cuda_stream, "stages", rows)
@@ -431,7 +431,4 @@ def _flush_weight_grads(wg, rows_of, R, main, side):
         # nothing downstream reads these gradients before the step ends (dp.GradientExchange.launch waits for the side
         # stream itself): join at the end of backward instead of stalling the main stream for the 4.5 ms grouped launch
         # (a kernel trace showed the encoder backward waiting for it)
-        if ops.WGRAD_JOIN_AT_END:
-            ops._arm_side_join()
-        else:
-            main.wait_stream(run)
+        ops._arm_side_join()

@@ -41,6 +41,31 @@ def test_round_trip_and_frontend_only_file(tmp_path):
         checkpoint.save_checkpoint(tmp_path / "bad.pt", a, thing=object())
 
 
+def test_torch_adam_state_round_trips(tmp_path):
+    """The reference's optimizer (torch.optim.Adam inside TransformerOptimizer, SBL/train.py:75): its nested state dict is
+    saved and restored, so a resume continues with the moments and the Noam step it stopped at."""
+    from sbl_for_multilingual_lip_reading_amd import checkpoint
+    from sbl_for_multilingual_lip_reading_amd.transformer.optimizer import TransformerOptimizer
+    a = _model(1)
+    opt = TransformerOptimizer(torch.optim.Adam(a.encoder.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9))
+    for _ in range(3):
+        opt.zero_grad()
+        sum((p * p).sum() for p in a.encoder.parameters()).backward()
+        opt.step()
+    checkpoint.save_checkpoint(tmp_path / "ck.pt", a, opt)
+    b = _model(1)
+    opt_b = TransformerOptimizer(torch.optim.Adam(b.encoder.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9))
+    checkpoint.load_checkpoint(tmp_path / "ck.pt", b, opt_b)
+    assert opt_b.step_num == 3
+    sa, sb = opt.optimizer.state_dict()["state"], opt_b.optimizer.state_dict()["state"]
+    assert len(sa) == len(sb) > 0
+    for k in sa:
+        assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"])
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 3.0
+    with pytest.raises(TypeError):
+        checkpoint._to_cpu({"x": object()})
+
+
 class _Evil:
     def __reduce__(self):
         return (print, ("a pickled object of a checkpoint ran code",))

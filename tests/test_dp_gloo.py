@@ -43,19 +43,27 @@ def _worker(rank, world, port, overlap, q):
     mha._fuse()                                      # no-op now
     assert mha.w_qs.weight.data_ptr() >= flat.flat_param.data_ptr()
     dp.broadcast_parameters(flat)
-    ex = dp.GradientExchange(flat, world, overlap=overlap)
+    # small buckets so that every segment goes out as several all-reduces; the "sum" variant leaves the 1/world to the
+    # optimizer (FusedAdam(grad_scale=1/world))
+    ex = dp.GradientExchange(flat, world, overlap=overlap, average=(overlap != "sum"), bucket_bytes=1 << 20)
     flat.zero_grad()
     # "backward": every parameter's gradient = (rank+1) * its index pattern, accumulated in place like AccumulateGrad
     for i, (n, p) in enumerate(m.named_parameters()):
         p.grad.add_(float(rank + 1) * (1.0 + (i % 7)))
     if overlap:                                      # fire the segment launches in backward order, like the hooks do
-        assert len(ex._hooks) == 2
-        ex.launch("decoder.")
-        ex.launch("encoder.")
+        assert len(ex._hooks) == 5                   # encoder out, frontend out, inputs of ResNet stages 4, 3, 2
+        for seg in dp.FlatModel.SEGMENTS[:-1]:
+            ex.launch(seg)
+        ex.launch("decoder.")                        # idempotent within a step
     ex.finish()
+    # reverse-autograd order, <= 1 MB each, every element exactly once
+    order = [s for s, _ in ex.launches]
+    assert [s for i, s in enumerate(order) if i == 0 or order[i - 1] != s] == list(dp.FlatModel.SEGMENTS)
+    assert max(n for _, n in ex.launches) * 4 <= 1 << 20 and sum(n for _, n in ex.launches) == flat.numel
+    assert flat.ranges["visual_frontend."][1] - flat.ranges["visual_frontend."][0] < 200000      # layer1 + stem trail
     ok = True
     for i, (n, p) in enumerate(m.named_parameters()):
-        want = (1.0 + (i % 7)) * (1 + 2) / 2.0       # mean over ranks of (rank+1)*pattern
+        want = (1.0 + (i % 7)) * (1 + 2) / (1.0 if overlap == "sum" else 2.0)       # sum / mean over ranks of (rank+1)*pattern
         ok = ok and bool(torch.allclose(p.grad, torch.full_like(p.grad, want)))
     chk = flat.flat_param.double().sum().item()
     q.put((rank, ok, chk, flat.numel))
@@ -84,3 +92,7 @@ def test_dp_flat_allreduce_world2():
 
 def test_dp_overlap_hooks_world2():
     _run(True, 29612)
+
+
+def test_dp_sum_mode_world2():
+    _run("sum", 29613)

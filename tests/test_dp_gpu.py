@@ -98,3 +98,28 @@ def test_two_ranks_exchange_equals_mean_of_shard_gradients(tmp_path):
         d = float((got[0][a:b].double() - mean[a:b]).norm() / mean[a:b].norm())
         # frontend gradients pass through 17 train-mode BatchNorms at batch 2: 3e-2 there
         assert d < (3e-2 if seg.startswith("visual") else 2e-3), (seg, d)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_bench_two_ranks_rehearsal(mode):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two
+    ranks on the one GPU over gloo (RCCL needs one device per rank): both ways of issuing the step - the eager step with
+    the exchange launched from hooks inside backward, and graph replay with the two-graph cut at the frontend features
+    and the decoder / encoder all-reduces between the replays.  One JSON line from rank 0, n_gpus = 2, a finite loss."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (0 if mode == "eager" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--batch", "4", "--coin-patterns", "2", "--no-cpu-baseline", "--no-kernel-timing", "--mode", mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["issue"] == mode and d["config"]["global_batch"] == 8
+    assert d["config"]["graphs_per_step"] == (2 if mode == "graph" else 1) or mode == "eager"
+    assert d["config"]["loss"] == d["config"]["loss"] and 0 < d["config"]["loss"] < 100      # finite

@@ -984,7 +984,7 @@ def test_backward_cut_at_frontend_features_equals_single_backward(ops):
             loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
             loss.backward()
             ops.join_side_streams()
-            a, b = flat.ranges["visual_frontend."]
+            a, b = flat.span("visual_frontend.")
             assert float(flat.flat_grad[a:b].abs().max()) == 0.0          # nothing reached the frontend yet
             feats.backward(feats_d.grad)
         ops.join_side_streams()
@@ -1053,11 +1053,51 @@ def test_fused_adam_training_steps_match_torch_adam(ops):
     # analytically-zero K-bias gradients, BN-amplified frontend noise) can take the opposite sign in the two
     # summation orders, so compare the matrices of the transformer in relative L2, not element-wise.  Two runs of the
     # SAME optimizer differ by 1e-5 or by 2.6e-3 depending on whether such a flip happens (float-atomic summation
-    # order; measured with tools/debug_adam.py), hence the 1e-2 bound.
+    # order), hence the 1e-2 bound.
     for n, p in m2.named_parameters():
         if (n.startswith("decoder") or n.startswith("encoder")) and p.dim() >= 2:
             num = float((p - p1[n]).norm())
             assert num < 1e-2 * float(p1[n].norm()) + 1e-6, (n, num)
+
+
+def test_flat_model_with_torch_adam_and_default_zero_grad(ops):
+    """dp.FlatModel under a FOREIGN optimizer: torch.optim.Adam's zero_grad() defaults to set_to_none=True, which drops the
+    `.grad` views of the flat gradient buffer the kernels accumulate into.  ops._gbuf / FlatModel.reattach must restore
+    them (zeroed) at the start of the next backward, so that Adam sees every gradient: the trajectory equals FusedAdam's,
+    and decoder / encoder weights move (they would stay put if `.grad` stayed None)."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    from sbl_for_multilingual_lip_reading_amd.transformer.optimizer import FusedAdam, TransformerOptimizer
+    B, T, H, W, ne, nd = 2, 4, 24, 24, 1, 1
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 52)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    m1, m2 = build_model(ne, nd).train(), build_model(ne, nd).train()
+    f1, f2 = dp.FlatModel(m1), dp.FlatModel(m2)
+    start = f1.flat_param.clone()
+    opt1 = TransformerOptimizer(torch.optim.Adam(m1.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-09), warmup_steps=2, k=0.5)
+    opt2 = TransformerOptimizer(FusedAdam(f2, betas=(0.9, 0.98), eps=1e-09), warmup_steps=2, k=0.5)
+    for step in range(3):
+        for m, opt in ((m1, opt1), (m2, opt2)):
+            random.seed(200 + step)
+            opt.zero_grad()                       # torch: every p.grad becomes None
+            pl, gl, pr, gr = m(xd, ld, rd)
+            loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+            loss.backward()
+            ops.join_side_streams()
+            opt.step()
+        # after backward every parameter's .grad is its slice of the flat buffer again
+        assert all(p.grad is not None and p.grad.data_ptr() == p._sbl_grad.data_ptr() for p in m1.parameters())
+    for seg in ("decoder.", "encoder."):
+        a, b = f1.ranges[seg]
+        assert float((f1.flat_param[a:b] - start[a:b]).abs().max()) > 1e-4          # Adam did step these
+    p2 = dict(m2.named_parameters())
+    for n, p in m1.named_parameters():
+        if (n.startswith("decoder") or n.startswith("encoder")) and p.dim() >= 2:
+            assert float((p - p2[n]).norm()) < 1e-2 * float(p2[n].norm()) + 1e-6, n       # (bound: see the test above)
+    # an assigned foreign gradient is adopted, not lost
+    w = m1.encoder.linear_in.weight
+    w.grad = torch.full_like(w, 3.0)
+    assert ops._gbuf(w).data_ptr() == w.grad.data_ptr() and float(w._sbl_grad.mean()) == 3.0
 
 
 def test_frozen_encoder_stage_is_honoured(ops):
@@ -1211,7 +1251,7 @@ def test_full_size_step_properties(ops):
         return float(loss), flat.flat_grad.clone(), pl.detach().clone()
 
     def rel(a, b, seg):
-        lo, hi = flat.ranges[seg]
+        lo, hi = flat.span(seg)
         return float((a[lo:hi] - b[lo:hi]).norm() / b[lo:hi].norm())
 
     l1, g1, p1 = run(True)
