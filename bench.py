@@ -159,7 +159,7 @@ class LaunchRecorder:
                 fl = sum(2.0 * a[7][p] * a[8][p] * rows for p in range(a[0]))
                 by = sum(4.0 * ((a[7][p] + a[8][p]) * rows + 2 * a[7][p] * a[8][p]) for p in range(a[0]))
             elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_dgrad_bnstats", "sbl_conv2d_wgrad"):
-                off = 1 if name == "sbl_conv2d_fwd" else 0
+                off = 2 if name == "sbl_conv2d_fwd" else 0
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
                 ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin

@@ -125,7 +125,8 @@ int sbl_stem_wgrad(const float* x, const float* conv_out, const float* dpooled, 
 /* ---------------------------------------------------------------- BatchNorm (train / eval)
  * nn.BatchNorm{2,3}d defaults: SBL/transformer/video_frontend.py:21,24,71,101. */
 int sbl_bn_finalize(const double* stats /*[2C]*/, long count, float* running_mean, float* running_var,
-                    float momentum, float eps, float* save_mean, float* save_invstd, int C, sbl_stream_t stream);
+                    float momentum, float eps, float* save_mean, float* save_invstd, int C,
+                    int64_t* num_batches_tracked /* += 1, or NULL */, sbl_stream_t stream);
 int sbl_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd,
                       int C, sbl_stream_t stream);
 /* y = [relu]( gamma*(x-mean)*invstd + beta [+ res] ), NHWC rows x C */
@@ -147,14 +148,15 @@ int sbl_bn_bwd_apply(const float* dy, const float* y, const float* x, const floa
  * Weights are used in OHWI order [Cout][KH][KW][Cin]; pack/unpack convert from/to the
  * reference's OIHW parameter layout (state-dict shapes stay the reference's). */
 int sbl_conv_weight_pack(const float* w_oihw, float* w_ohwi, float* w_dgrad /*[Cin][KH][KW][Cout] or NULL*/, int Cout,
-                         int Cin, int KH, int KW, sbl_stream_t stream);
+                         int Cin, int KH, int KW, double* zero /* nzero doubles set to 0 by the same launch (the BN
+                         statistics of the convolution that follows), or NULL */, int nzero, sbl_stream_t stream);
 /* accumulate != 0: dw_oihw += (the persistent flat gradient buffer of a data-parallel replica) */
 int sbl_conv_wgrad_unpack(const float* dw_ohwi, float* dw_oihw, int Cout, int Cin, int KH, int KW, int accumulate,
                           sbl_stream_t stream);
-/* stats: NULL or double[2*Cout] (sum, sumsq of y) accumulated by the epilogue; zeroed by the call.
+/* stats: NULL or double[2*Cout] (sum, sumsq of y) accumulated by the epilogue; zeroed by the call unless stats_zeroed.
  * ws / ws_bytes (may be NULL/0): the calling stream's sbl_gemm_f32 workspace.  With it, a launch whose tile count
  * is not a multiple of the 256 CUs runs its last partial round of tiles split along K (in-launch slab reduction). */
-int sbl_conv2d_fwd(const float* x, const float* w_ohwi, float* y, double* stats, int NIMG, int H, int W, int Cin,
+int sbl_conv2d_fwd(const float* x, const float* w_ohwi, float* y, double* stats, int stats_zeroed, int NIMG, int H, int W, int Cin,
                    int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream);
 int sbl_conv2d_dgrad(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream);

@@ -19,14 +19,14 @@ SIGNATURES = {
     "sbl_stem_bn_relu_pool_fwd": [P, P, P, P, P, P, P, I, I, I, P],
     "sbl_stem_bwd_reduce": [P, P, P, P, P, P, P, P, I, I, I, P],
     "sbl_stem_wgrad": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
-    "sbl_bn_finalize": [P, L, P, P, F, F, P, P, I, P],
+    "sbl_bn_finalize": [P, L, P, P, F, F, P, P, I, P, P],
     "sbl_bn_eval_stats": [P, P, F, P, P, I, P],
     "sbl_bn_apply_fwd": [P, P, P, P, P, P, P, L, I, I, P],
     "sbl_bn_bwd_reduce": [P, P, P, P, P, P, L, I, I, P, L, P],
     "sbl_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
-    "sbl_conv_weight_pack": [P, P, P, I, I, I, I, P],
+    "sbl_conv_weight_pack": [P, P, P, I, I, I, I, P, I, P],
     "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, I, P],
-    "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_dgrad_bnstats": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P],
     "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],

@@ -27,8 +27,8 @@ static inline bool conv_pm_ok(int Ho, int Wo, int KH, int stride) { return KH ==
 
 #define SBL_CONV_WS_COUNTERS 4096      // same workspace convention as sbl_gemm_f32: int counters, then fp32 slabs
 constexpr int g_tailsplit = 1;
-extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* stats, int NIMG, int H, int W, int Cin,
-                              int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
+extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* stats, int stats_zeroed, int NIMG, int H, int W,
+                              int Cin, int Cout, int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_conv("sbl_conv2d_fwd", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(x && w && y && sbl_aligned16(x) && sbl_aligned16(w), "sbl_conv2d_fwd: null/unaligned pointer");
@@ -36,7 +36,7 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     const int M = NIMG * Ho * Wo, N = Cout, K = KH * KW * Cin;
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     sbl_geom_finish(g);
-    if (stats) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
+    if (stats && !stats_zeroed) SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * Cout, s));
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_fwd: workspace unaligned or < 16 KiB");
 #define SBL_CONV_FWD(BM, BN, WN)                                                                               \
@@ -290,8 +290,9 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
 // ------------------------------------------------------------------ weight layout
 // OIHW (state-dict layout) -> OHWI [Cout][KH][KW][Cin]  (+ dgrad operand [Cin][KH][KW][Cout])
 __global__ void weight_pack_kernel(const float* __restrict__ w, float* __restrict__ ohwi, float* __restrict__ wt,
-                                   int Cout, int Cin, int KH, int KW) {
+                                   int Cout, int Cin, int KH, int KW, double* __restrict__ zero, int nzero) {
     long n = (long)Cout * Cin * KH * KW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0.0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         // i indexes OHWI
         int ci = i % Cin;
@@ -321,11 +322,11 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ ohwi, float* __res
     }
 }
 extern "C" int sbl_conv_weight_pack(const float* w, float* ohwi, float* wt, int Cout, int Cin, int KH, int KW,
-                                    sbl_stream_t stream) {
-    SBL_REQUIRE(w && ohwi && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "sbl_conv_weight_pack: bad args");
+                                    double* zero, int nzero, sbl_stream_t stream) {
+    SBL_REQUIRE(w && ohwi && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && nzero >= 0 && (zero || !nzero), "sbl_conv_weight_pack: bad args");
     long n = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(weight_pack_kernel, dim3(sbl_cdiv(n, 256) > 2048 ? 2048 : sbl_cdiv(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, ohwi, wt, Cout, Cin, KH, KW);
+                       (hipStream_t)stream, w, ohwi, wt, Cout, Cin, KH, KW, zero, nzero);
     SBL_LAUNCH_CHECK("sbl_conv_weight_pack");
     return 0;
 }

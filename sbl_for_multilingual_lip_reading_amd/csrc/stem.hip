@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
 // ------------------------------------------------------------------ BN finalize (shared with the trunk)
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, long count, float* running_mean,
                                    float* running_var, float momentum, float eps, float* save_mean, float* save_invstd,
-                                   int C) {
+                                   int C, long long* num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;      // nn.BatchNorm's counter, no launch of its own
     const double mean = stats[c] / (double)count;
     double var = stats[C + c] / (double)count - mean * mean;
     if (var < 0) var = 0;
@@ -387,11 +388,12 @@ extern "C" int sbl_stem_conv_fwd(const float* x, const float* w, float* conv_out
 }
 
 extern "C" int sbl_bn_finalize(const double* stats, long count, float* running_mean, float* running_var, float momentum,
-                               float eps, float* save_mean, float* save_invstd, int C, sbl_stream_t stream) {
+                               float eps, float* save_mean, float* save_invstd, int C, int64_t* num_batches_tracked,
+                               sbl_stream_t stream) {
     SBL_REQUIRE(stats && save_mean && save_invstd && C > 0 && count > 0, "sbl_bn_finalize: bad args");
     SBL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sbl_bn_finalize: running stats must both be set or both null");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(sbl_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, count,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, C);
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, C, (long long*)num_batches_tracked);
     SBL_LAUNCH_CHECK("sbl_bn_finalize");
     return 0;
 }

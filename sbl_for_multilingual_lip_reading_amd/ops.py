@@ -958,7 +958,8 @@ class StemFn(torch.autograd.Function):
     """frontend3D (video_frontend.py:99-104) on (N,T,H,W) clips -> pooled NHWC (N*T, H/4, W/4, 64)."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, momentum, eps, nbt=None):
+        """nbt: the BatchNorm's num_batches_tracked (int64 scalar) or None; incremented by the finalize kernel."""
         _need_cuda(x, w, gamma, beta)
         x = x.contiguous()
         N, T, H, W = x.shape
@@ -972,7 +973,7 @@ class StemFn(torch.autograd.Function):
         invstd = torch.empty(64, device=dev, dtype=torch.float32)
         if training:
             call("sbl_bn_finalize", _p(stats), N * T * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps, _p(mean),
-                 _p(invstd), 64, _s())
+                 _p(invstd), 64, _p(nbt), _s())
         else:
             call("sbl_bn_eval_stats", _p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), 64, _s())
         pooled = torch.empty(N * T, Ho // 2, Wo // 2, 64, device=dev, dtype=torch.float32)
@@ -999,7 +1000,7 @@ class StemFn(torch.autograd.Function):
         dbeta = torch.empty(64, device=dev, dtype=torch.float32)
         call("sbl_stem_wgrad", _p(x), _p(conv), _p(dpooled), _p(argmax), _p(mean), _p(invstd), _p(gamma), _p(beta),
              _p(sums), _p(dw), _p(dgamma), _p(dbeta), N, T, H, W, _s())
-        return None, dw.view(64, 1, 5, 7, 7), dgamma, dbeta, None, None, None, None, None
+        return None, dw.view(64, 1, 5, 7, 7), dgamma, dbeta, None, None, None, None, None, None
 
 
 class ConvBNFn(torch.autograd.Function):
@@ -1008,7 +1009,7 @@ class ConvBNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, relu, stride, training, momentum, eps, box_out=None,
-                box_in=None):
+                box_in=None, nbt=None):
         """box_out / box_in (dicts or None) link conv1 -> bn1 -> relu to the conv2 that consumes it (BasicBlock,
         video_frontend.py:31-35): this node publishes (pre-BN output, mean, invstd) in box_out; the consumer, given the same
         dict as box_in, computes bn1's backward reduction in the epilogue of its input-gradient convolution
@@ -1024,18 +1025,19 @@ class ConvBNFn(torch.autograd.Function):
         w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         # the input-gradient layout [Cin][kh][kw][Cout] is packed by the same launch and kept for backward
         w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if (training and ctx.needs_input_grad[0]) else None
-        call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
+        # (the pack launch also zeroes the BN statistics the convolution's epilogue accumulates into)
+        stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64) if training else None
+        call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _p(stats), 2 * Cout if training else 0, _s())
         conv = torch.empty(NIMG, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         mean = torch.empty(Cout, device=dev, dtype=torch.float32)
         invstd = torch.empty(Cout, device=dev, dtype=torch.float32)
         if training:
-            stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
-            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), _p(stats), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), _p(stats), 1, NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                  _workspace().data_ptr(), WS_BYTES, _s())
             call("sbl_bn_finalize", _p(stats), NIMG * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps, _p(mean),
-                 _p(invstd), Cout, _s())
+                 _p(invstd), Cout, _p(nbt), _s())
         else:
-            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), None, NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+            call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), None, 0, NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                  _workspace().data_ptr(), WS_BYTES, _s())
             call("sbl_bn_eval_stats", _p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), Cout, _s())
         y = torch.empty_like(conv)
@@ -1089,7 +1091,7 @@ class ConvBNFn(torch.autograd.Function):
             if w_dg is None:
                 w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
                 w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
-                call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _s())
+                call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, None, 0, _s())
             dx = torch.empty_like(x)
             bi = ctx.box_in
             if bi is not None and bi.get("conv") is not None:
@@ -1115,15 +1117,15 @@ class ConvBNFn(torch.autograd.Function):
             x.record_stream(side)
             dconv.record_stream(side)
             _arm_side_join()
-            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
         dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
         if gw is not None:
             call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
-            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
         dw = torch.empty_like(w)
         call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(dw), Cout, Cin, KH, KW, 0, _s())
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
 class AvgPoolFn(torch.autograd.Function):

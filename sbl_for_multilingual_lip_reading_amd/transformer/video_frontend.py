@@ -19,10 +19,9 @@ def conv3x3(in_planes, out_planes, stride=1):
 
 def _conv_bn(x, conv, bn, res, relu, training, box_out=None, box_in=None):
     """conv -> BatchNorm2d -> (+res) -> (ReLU), NHWC, one tape node; BN side effects like nn.BatchNorm2d."""
-    if training:
-        bn.num_batches_tracked.add_(1)
     return ops.ConvBNFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu,
-                              conv.stride[0], training, bn.momentum, bn.eps, box_out, box_in)
+                              conv.stride[0], training, bn.momentum, bn.eps, box_out, box_in,
+                              bn.num_batches_tracked if training else None)      # (+= 1 inside the finalize kernel)
 
 
 class BasicBlock(nn.Module):
@@ -118,10 +117,8 @@ class Lipreading(nn.Module):
         if x.dim() == 5:
             x = x[:, 0]
         conv, bn = self.frontend3D[0], self.frontend3D[1]
-        if self.training:
-            bn.num_batches_tracked.add_(1)
         x = ops.StemFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
-                             bn.momentum, bn.eps)
+                             bn.momentum, bn.eps, bn.num_batches_tracked if self.training else None)
         return self.resnet18(x)
 
     def forward(self, x):

@@ -180,14 +180,14 @@ def test_conv2d_fwd_dgrad_wgrad(ops, NIMG, H, W, Cin, Cout, k, stride):
     xd, wd, dyd = _nhwc(x.detach()).to(DEV), w.detach().to(DEV), _nhwc(dy).to(DEV)
     w_ohwi = torch.empty(Cout, k, k, Cin, device=DEV)
     w_dg = torch.empty(Cin, k, k, Cout, device=DEV)
-    ops.call("sbl_conv_weight_pack", wd.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, Cin, k, k, ops._s())
+    ops.call("sbl_conv_weight_pack", wd.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, Cin, k, k, None, 0, ops._s())
     assert maxdiff(w_ohwi, w.detach().permute(0, 2, 3, 1)) == 0 and maxdiff(w_dg, w.detach().permute(1, 2, 3, 0)) == 0
     yd = torch.empty(NIMG, Ho, Wo, Cout, device=DEV)
     stats = torch.empty(2 * Cout, device=DEV, dtype=torch.float64)
     # with the stream workspace the launches whose tile count leaves a partial last round split that round along K
     # (the (40, 22, 22, 64, 64) and (20, 22, 22, 128, 128) cases: 303 / 304 tiles -> 256 unsplit + 47 / 48 split 5 ways)
     ws = ops._workspace()
-    ops.call("sbl_conv2d_fwd", xd.data_ptr(), w_ohwi.data_ptr(), yd.data_ptr(), stats.data_ptr(), NIMG, H, W, Cin, Cout,
+    ops.call("sbl_conv2d_fwd", xd.data_ptr(), w_ohwi.data_ptr(), yd.data_ptr(), stats.data_ptr(), 0, NIMG, H, W, Cin, Cout,
              k, k, stride, pad, ws.data_ptr(), ops.WS_BYTES, ops._s())
     K = Cin * k * k
     tol = 4e-7 * K ** 0.5 * 4
@@ -220,7 +220,7 @@ def test_dgrad_epilogue_reduces_the_next_batchnorm_backward(ops, NIMG, H, W, C, 
     inv = (U("bs_is%d" % C, (C,), 0.2) + 1.0).to(DEV)
     act = ((pre - mean) * inv).clamp_min(0).contiguous()
     w_ohwi, w_dg = torch.empty(Cout, 3, 3, C, device=DEV), torch.empty(C, 3, 3, Cout, device=DEV)
-    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, C, 3, 3, ops._s())
+    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, C, 3, 3, None, 0, ops._s())
     ws = ops._workspace()
     dx0, dx1 = torch.empty(NIMG, H, W, C, device=DEV), torch.empty(NIMG, H, W, C, device=DEV)
     ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx0.data_ptr(), NIMG, H, W, C, Cout, 3, 3, 1, 1, ws.data_ptr(), ops.WS_BYTES, ops._s())

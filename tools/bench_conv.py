@@ -23,14 +23,14 @@ for name, H, Cin, Cout, k, stride in [("layer1", 22, 64, 64, 3, 1), ("layer2", 1
     Ho = (H + 2 * pad - k) // stride + 1
     x = torch.randn(NIMG, H, H, Cin, device=dev); w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
     w_ohwi = torch.empty(Cout, k, k, Cin, device=dev); w_dg = torch.empty(Cin, k, k, Cout, device=dev)
-    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, Cin, k, k, ops._s())
+    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, Cin, k, k, None, 0, ops._s())
     y = torch.empty(NIMG, Ho, Ho, Cout, device=dev); stats = torch.zeros(2 * Cout, device=dev, dtype=torch.float64)
     sp = None if os.environ.get("NOSTATS") else stats.data_ptr()
     dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty(Cout, k, k, Cin, device=dev)
     fl = 2.0 * NIMG * Ho * Ho * Cout * Cin * k * k / 1e6
     for prec in precs:
         ops.set_matmul_precision(prec)
-        t1 = timeit(lambda: ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), sp, NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
+        t1 = timeit(lambda: ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), sp, 0, NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
         t2 = timeit(lambda: ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
         t3 = timeit(lambda: ops.call("sbl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._s()))
         print("%-8s %-6s %5.1f GF  fwd %7.1f us (%5.1f TF)  dgrad %7.1f us (%5.1f TF)  wgrad %7.1f us (%5.1f TF)" % (name, prec, fl / 1e3, t1, fl / t1, t2, fl / t2, t3, fl / t3), flush=True)

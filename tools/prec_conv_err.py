@@ -20,13 +20,13 @@ for (NIMG, H, W, Cin, Cout, k, stride) in shapes:
     Ho, Wo = y.shape[2:]
     xd, wd, dyd = nhwc(x.detach()).to(DEV), w.detach().to(DEV), nhwc(dy).to(DEV)
     w_ohwi = torch.empty(Cout, k, k, Cin, device=DEV); w_dg = torch.empty(Cin, k, k, Cout, device=DEV)
-    ops.call("sbl_conv_weight_pack", wd.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, Cin, k, k, ops._s())
+    ops.call("sbl_conv_weight_pack", wd.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), Cout, Cin, k, k, None, 0, ops._s())
     ws = ops._workspace()
     line = "%4dx%2dx%2d c%3d->%3d k%d s%d |" % (NIMG, H, W, Cin, Cout, k, stride)
     for mode in ("f32", "bf16x6", "bf16x3"):
         ops.set_matmul_precision(mode)
         yd = torch.empty(NIMG, Ho, Wo, Cout, device=DEV)
-        ops.call("sbl_conv2d_fwd", xd.data_ptr(), w_ohwi.data_ptr(), yd.data_ptr(), None, NIMG, H, W, Cin, Cout, k, k, stride, pad, ws.data_ptr(), ops.WS_BYTES, ops._s())
+        ops.call("sbl_conv2d_fwd", xd.data_ptr(), w_ohwi.data_ptr(), yd.data_ptr(), None, 0, NIMG, H, W, Cin, Cout, k, k, stride, pad, ws.data_ptr(), ops.WS_BYTES, ops._s())
         dxd = torch.empty_like(xd)
         ops.call("sbl_conv2d_dgrad", dyd.data_ptr(), w_dg.data_ptr(), dxd.data_ptr(), NIMG, H, W, Cin, Cout, k, k, stride, pad, ws.data_ptr(), ops.WS_BYTES, ops._s())
         dwd = torch.empty(Cout, k, k, Cin, device=DEV)
