@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
                                                             int mask_kind, const uint8_t* __restrict__ mask, int B, int H,
                                                             SegDesc segs, int Lk_fixed, float scale, uint32_t thresh,
                                                             float keep_scale, const uint64_t* __restrict__ seed,
-                                                            uint64_t offset) {
+                                                            uint64_t offset, unsigned long long* stamp) {
+    sbl_stamp_begin(stamp);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Qs = smem, *Ks = smem + AT_SZ, *Vs = smem + 2 * AT_SZ, *Ss = smem + 3 * AT_SZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
             if (i < Lq) og[(long)i * ldo + j0 + (lane & 31)] = acc[r];
         }
     }
+    sbl_stamp_end(stamp);
 }
 
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ dout, long lddo, const float* __restrict__ q,
@@ -114,7 +116,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                                                             float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
                                                             float* __restrict__ dv, long lddv, int B, int H, SegDesc segs,
                                                             int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
-                                                            const uint64_t* __restrict__ seed, uint64_t offset) {
+                                                            const uint64_t* __restrict__ seed, uint64_t offset, unsigned long long* stamp) {
+    sbl_stamp_begin(stamp);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Qs = smem, *Ks = smem + AT_SZ, *Vs = smem + 2 * AT_SZ, *Gs = smem + 3 * AT_SZ, *Ps = smem + 4 * AT_SZ,
           *Ds = smem + 5 * AT_SZ;   // Gs = dO, Ps = (dropped) P then dS, Ds = dP
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
             }
         }
     }
+    sbl_stamp_end(stamp);
 }
 
 // ------------------------------------------------------------------ decoder-sized problems: one wavefront each
@@ -658,7 +662,7 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
     if (int e = at_attr((const void*)attention_fwd_kernel, lds, attr_set)) return e;
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(nseg * B * H), dim3(256), lds, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, o,
                        ldo, p_out, mask_kind, mask, B, H, d, Lk_fixed, scale, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
-                       1.f / (1.f - drop_p), seed, offset);
+                       1.f / (1.f - drop_p), seed, offset, sbl_next_stamp_slot(SBL_KID_ATTENTION));
     SBL_LAUNCH_CHECK("sbl_attention_fwd");
     return 0;
 }
@@ -733,7 +737,7 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
     if (int e = at_attr((const void*)attention_bwd_kernel, lds, attr_set)) return e;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(nseg * B * H), dim3(256), lds, (hipStream_t)stream, dout, lddo, q, ldq, k, ldk,
                        v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
-                       drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset);
+                       drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, sbl_next_stamp_slot(SBL_KID_ATTENTION));
     SBL_LAUNCH_CHECK("sbl_attention_bwd");
     return 0;
 }

@@ -54,6 +54,8 @@ __device__ __forceinline__ void sbl_stamp_end(unsigned long long* slot) {
 #define SBL_KID_CONV_DGRAD 5
 #define SBL_KID_CONV_WGRAD 6
 #define SBL_KID_SEG_WGRAD 7
+#define SBL_KID_STEM 8
+#define SBL_KID_ATTENTION 9
 
 // ---- ragged row batches: a "run" of decoder steps whose inputs are all known is processed as one batch of
 // segments; segment s holds B sequences of length L[s], rows [row_off[s], row_off[s] + B*L[s]) in (b, l) order.

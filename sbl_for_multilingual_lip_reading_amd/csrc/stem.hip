@@ -49,7 +49,8 @@ __device__ __forceinline__ void st_load_patch(float* patch, const float* __restr
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ out, double* __restrict__ stats, int N,
                                                             int T, int H, int W, int Ho, int Wo, int TY, int TX,
-                                                            int ntiles) {
+                                                            int ntiles, unsigned long long* stamp) {
+    sbl_stamp_begin(stamp);
     __shared__ float Ws[ST_KP * ST_WS];
     __shared__ float patch[ST_PT * ST_PFS];
     float (*red)[128] = reinterpret_cast<float (*)[128]>(patch);   // reused after the tile loop: 80.8 KB total => 2 WG/CU
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     }
     __syncthreads();
     if (tid < 128) atomicAdd(stats + tid, (double)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+    sbl_stamp_end(stamp);
 }
 
 // ------------------------------------------------------------------ BN finalize (shared with the trunk)
@@ -153,7 +155,8 @@ __global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __r
                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ pooled,
                                                                 uint8_t* __restrict__ argmax, int NT, int Ho, int Wo, int Hp,
-                                                                int Wp) {
+                                                                int Wp, unsigned long long* stamp) {
+    sbl_stamp_begin(stamp);
     const long total = (long)NT * Hp * Wp * 16;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c4 = (int)(i & 15) * 4;
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __r
         *reinterpret_cast<uint32_t*>(argmax + (i >> 4) * 64 + c4) =
             (uint32_t)bidx[0] | ((uint32_t)bidx[1] << 8) | ((uint32_t)bidx[2] << 16) | ((uint32_t)bidx[3] << 24);
     }
+    sbl_stamp_end(stamp);
 }
 
 // gradient w.r.t. the BN output at conv pixel (oh,ow), 4 channels: max-pool adjoint (gather over the <=4 windows
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const float* __res
                                                               const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, double* __restrict__ sums, int NT,
-                                                              int Ho, int Wo, int Hp, int Wp) {
+                                                              int Ho, int Wo, int Hp, int Wp, unsigned long long* stamp) {
+    sbl_stamp_begin(stamp);
     __shared__ float red[16][16][8];
     const int c4 = (threadIdx.x & 15) * 4;
     const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const float* __res
         const int ch = cq * 4 + (k & 3);
         atomicAdd(sums + (k < 4 ? ch : 64 + ch), (double)s);
     }
+    sbl_stamp_end(stamp);
 }
 
 // ------------------------------------------------------------------ backward pass 2: weight gradient
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                                                          const double* __restrict__ sums, float* __restrict__ dw,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int T,
                                                          int H, int W, int Ho, int Wo, int Hp, int Wp, int TY, int TX,
-                                                         int ntiles) {
+                                                         int ntiles, unsigned long long* stamp) {
+    sbl_stamp_begin(stamp);
     __shared__ __attribute__((aligned(16))) float Ds[128 * ST_DS];
     __shared__ float patch[ST_PT * ST_PFS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                 }
             }
         }
+    sbl_stamp_end(stamp);
 }
 
 // ------------------------------------------------------------------ host entry points
@@ -382,7 +390,7 @@ extern "C" int sbl_stem_conv_fwd(const float* x, const float* w, float* conv_out
     SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 128, s));
     const int grid = (int)(ntiles < 512 ? ntiles : 512);   // persistent: 2 workgroups per CU (LDS-bound)
     hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(grid), dim3(256), 0, s, x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY,
-                       TX, (int)ntiles);
+                       TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
     SBL_LAUNCH_CHECK("sbl_stem_conv_fwd");
     return 0;
 }
@@ -415,7 +423,7 @@ extern "C" int sbl_stem_bn_relu_pool_fwd(const float* conv_out, const float* mea
     const long total = (long)NT * Hp * Wp * 16;
     const int grid = (int)(sbl_cdiv(total, 256) > 8192 ? 8192 : sbl_cdiv(total, 256));
     hipLaunchKernelGGL(stem_bn_relu_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, conv_out, mean, invstd,
-                       gamma, beta, pooled, argmax, NT, Ho, Wo, Hp, Wp);
+                       gamma, beta, pooled, argmax, NT, Ho, Wo, Hp, Wp, sbl_next_stamp_slot(SBL_KID_STEM));
     SBL_LAUNCH_CHECK("sbl_stem_bn_relu_pool_fwd");
     return 0;
 }
@@ -430,7 +438,7 @@ extern "C" int sbl_stem_bwd_reduce(const float* conv_out, const float* dpooled, 
     const long npix = (long)NT * Ho * Wo;
     const int grid = (int)(sbl_cdiv(npix, 16) > 4096 ? 4096 : sbl_cdiv(npix, 16));
     hipLaunchKernelGGL(stem_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, conv_out, dpooled, argmax, mean, invstd, gamma,
-                       beta, sums, NT, Ho, Wo, Ho / 2, Wo / 2);
+                       beta, sums, NT, Ho, Wo, Ho / 2, Wo / 2, sbl_next_stamp_slot(SBL_KID_STEM));
     SBL_LAUNCH_CHECK("sbl_stem_bwd_reduce");
     return 0;
 }
@@ -449,7 +457,7 @@ extern "C" int sbl_stem_wgrad(const float* x, const float* conv_out, const float
     SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 64 * ST_K, s));
     const int grid = (int)(ntiles < 768 ? ntiles : 768);   // 3 workgroups per CU (52 KB LDS each)
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, conv_out, dpooled, argmax, mean, invstd, gamma,
-                       beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles);
+                       beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
     SBL_LAUNCH_CHECK("sbl_stem_wgrad");
     return 0;
 }
