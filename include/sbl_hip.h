@@ -168,6 +168,24 @@ int sbl_conv2d_dgrad_bnstats(const float* dy, const float* w_dgrad, float* dx, i
                              int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* act,
                              const float* pre, const float* mean, const float* invstd, double* sums,
                              sbl_stream_t stream);
+/* The general form (any stride; every fused operand may be NULL) - what BasicBlock's backward needs so that no separate
+ * pass touches dx (video_frontend.py:28-41):
+ *   addend  the residual branch's gradient, added before the store and the sums.  Stride 1: laid out like dx (identity
+ *           shortcut).  Stride 2: the COMPACT (NIMG, ceil(H/2), ceil(W/2), Cin) gradient of the 1x1 / stride-2 downsample
+ *           branch (sbl_conv1x1s2_dgrad_compact), which lives on the even/even pixels only.
+ *   act, pre, mean, invstd  as in sbl_conv2d_dgrad_bnstats: the BatchNorm whose output gradient dx (with the addend) is -
+ *           the previous block's bn2; sums[0..2Cin).
+ *   pre2, mean2, invstd2    a second BatchNorm fed through the same act (that block's downsample branch):
+ *           sums[2Cin..4Cin) = (sum g, sum g * (pre2 - mean2) * invstd2).  sums: double[2*Cin] or double[4*Cin]. */
+int sbl_conv2d_dgrad_fused(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                           int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* addend,
+                           const float* act, const float* pre, const float* mean, const float* invstd, const float* pre2,
+                           const float* mean2, const float* invstd2, double* sums, sbl_stream_t stream);
+/* Input gradient of the 1x1 / stride-2 downsample convolution on its own support: dx_compact (NIMG, ceil(H/2), ceil(W/2),
+ * Cin) = dy (NIMG, ceil(H/2), ceil(W/2), Cout) * w; the other three quarters of the full-size gradient are zeros that
+ * nobody needs to write (sbl_conv2d_dgrad_fused adds the compact form to conv1's gradient). */
+int sbl_conv1x1s2_dgrad_compact(const float* dy, const float* w_dgrad, float* dx_compact, int NIMG, int H, int W, int Cin,
+                                int Cout, void* ws, long ws_bytes, sbl_stream_t stream);
 /* dw_ohwi zeroed by the call, then split-K float atomics */
 int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, int NIMG, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad, sbl_stream_t stream);

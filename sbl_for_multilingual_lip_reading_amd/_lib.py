@@ -29,6 +29,8 @@ SIGNATURES = {
     "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_dgrad_bnstats": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P],
+    "sbl_conv2d_dgrad_fused": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P, P, P, P, P],
+    "sbl_conv1x1s2_dgrad_compact": [P, P, P, I, I, I, I, I, P, L, P],
     "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
     "sbl_avgpool_fwd": [P, P, I, I, I, P],
     "sbl_avgpool_bwd": [P, P, I, I, I, P],

@@ -99,30 +99,45 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
     return 0;
 }
 
-struct DgradBnStats {       // next BatchNorm backward's reduction riding on the epilogue (EpiStore::bs_*), or all nullptr
+// What may ride on an input-gradient convolution's epilogue (all optional):
+//   addend      the residual branch's gradient, added before the store: laid out like dx (identity shortcut), or - stride-2
+//               convolutions, add_class00 - the compact (NIMG, ceil(H/2), ceil(W/2), Cin) gradient of the 1x1 / stride-2
+//               downsample branch, which lives on the even/even pixels only (the rows of parity class (0,0));
+//   y,x,mean,inv the BatchNorm whose output gradient dx is (dx = d relu(bn(.)) of the producing block): its two backward
+//               sums over g = dx * (y > 0);  x2,mean2,inv2: a second BatchNorm fed by the same y (that block's
+//               downsample branch): sums[2C..4C) = (sum g, sum g * xhat2).
+struct DgradFuse {
+    const float* addend;
+    int add_class00;
     const float* y;
     const float* x;
     const float* mean;
     const float* inv;
+    const float* x2;
+    const float* mean2;
+    const float* inv2;
     double* sums;
 };
 static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream,
-                             const DgradBnStats& bs) {
+                             const DgradFuse& f, int compact_out) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_conv("sbl_conv2d_dgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(dy && wt && dx && sbl_aligned16(dy) && sbl_aligned16(wt), "sbl_conv2d_dgrad: null/unaligned pointer");
     const int Ho = out_dim(H, KH, stride, pad), Wo = out_dim(W, KW, stride, pad);
-    if (bs.sums) {
-        SBL_REQUIRE(stride == 1 && bs.y && bs.x && bs.mean && bs.inv, "sbl_conv2d_dgrad_bnstats: stride-1 convolutions only, all of y / x / mean / invstd");
-        SBL_HIP(hipMemsetAsync(bs.sums, 0, sizeof(double) * 2 * Cin, s));
+    const bool fused = f.addend || f.sums;
+    if (f.sums) {
+        SBL_REQUIRE(f.y && f.x && f.mean && f.inv && (!f.x2 || (f.mean2 && f.inv2)), "sbl_conv2d_dgrad_fused: incomplete BatchNorm operands");
+        SBL_HIP(hipMemsetAsync(f.sums, 0, sizeof(double) * (f.x2 ? 4 : 2) * Cin, s));
     }
+    SBL_REQUIRE(!f.addend || f.add_class00 == (stride == 2), "sbl_conv2d_dgrad_fused: the compact addend belongs to stride-2 convolutions (and only to them)");
+    SBL_REQUIRE(!compact_out || (KH == 1 && stride == 2 && !fused), "sbl_conv2d_dgrad: compact output is the 1x1 / stride-2 case");
     if (stride == 2) {
         // Input pixel (ih, iw) only receives taps with kh = ih + pad (mod 2), kw likewise: 1 + 2 + 2 + 4 of the 9 taps
         // over the four parity classes (3x3), or the even/even class alone (1x1).  One dense implicit GEMM per class
         // (rows = the class's pixels, k = its taps) does 1/4 of the work of gathering zeros for the other taps.
         const int N = Cin;
-        if (KH == 1) SBL_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)NIMG * H * W * Cin, s));
+        if (KH == 1 && !compact_out) SBL_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)NIMG * H * W * Cin, s));
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {
                 ConvGeom g{NIMG, (H - ph + 1) / 2, (W - pw + 1) / 2, Ho, Wo, Cout, KH, KW, stride, pad, 1, ph, pw, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -138,15 +153,28 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
                 if (g.ntaps == 0 || M == 0) continue;
                 SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
                 const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
+                const float* add = (f.addend && ph == 0 && pw == 0) ? f.addend : nullptr;
+                const int cmap = compact_out ? 0 : 1;
 #define SBL_CONV_DGC(BM, BN)                                                                                  \
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
         DenseKCTaps<BN> bl{wt, (long)KH * KW * Cout, N, Cout, {lin[0], lin[1], lin[2], lin[3]}};              \
-        EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 1, g.OH, g.OW, H, W, ph, pw};      \
-        sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+        if (f.sums) {                                                                                         \
+            EpiStore<0, true, true> e{dx, (long)N, nullptr, 0, f.sums, nullptr, 0, cmap, g.OH, g.OW, H, W, ph, pw, \
+                                      f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2, add, (long)N};          \
+            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, true, true>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+        } else if (fused) {                                                                                   \
+            EpiStore<0, false, true> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, cmap, g.OH, g.OW, H, W, ph, pw, \
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, add, (long)N}; \
+            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, false, true>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+        } else {                                                                                              \
+            EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, cmap, g.OH, g.OW, H, W, ph, pw}; \
+            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+        }                                                                                                     \
     } while (0)
-                if (N >= 128 && t128 >= 512) SBL_CONV_DGC(128, 128);
-                else if (N < 128 && (long)sbl_cdiv(M, 128) >= 512) SBL_CONV_DGC(128, 64);
+                // (the 128x128 tile with the fused statistics epilogue needs > 168 registers: one wave per SIMD; 128x64 instead)
+                if (N >= 128 && t128 >= 512 && !f.sums) SBL_CONV_DGC(128, 128);
+                else if ((N < 128 || f.sums) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DGC(128, 64);
                 else SBL_CONV_DGC(64, 64);
 #undef SBL_CONV_DGC
                 SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(class)");
@@ -159,7 +187,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_dgrad: workspace unaligned or < 16 KiB");
     if (conv_pm_ok(H, W, KH, stride)) {
-#define SBL_KPM_T_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, true>, BM_, BN_, true, P>
+#define SBL_KPM_T_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, true, true>, BM_, BN_, true, P>
+#define SBL_KPM_A_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, false, true>, BM_, BN_, true, P>
 #define SBL_KPM_F_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, false>, BM_, BN_, true, P>
 #define SBL_CONV_DG_PM(BM, BN)                                                                                 \
     do {                                                                                                       \
@@ -168,9 +197,14 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
         DenseKCTapList<BN> bl{wt, (long)K, N, Cout, 0ull};                                                     \
         SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};                       \
         dim3 grid(sbl_cdiv(N, BN), sbl_cdiv(M, BM), 1);                                                        \
-        if (bs.sums) {                                                                                         \
-            EpiStore<0, true> e{dx, (long)N, nullptr, 0, bs.sums, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0, bs.y, bs.x, bs.mean, bs.inv}; \
+        if (f.sums) {                                                                                          \
+            EpiStore<0, true, true> e{dx, (long)N, nullptr, 0, f.sums, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0, \
+                                      f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2, f.addend, 0L};           \
             SBL_PREC_LAUNCH(SBL_KPM_T_, grid, s, al, bl, e, sc, M, N);                                        \
+        } else if (f.addend) {                                                                                 \
+            EpiStore<0, false, true> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0, \
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f.addend, 0L}; \
+            SBL_PREC_LAUNCH(SBL_KPM_A_, grid, s, al, bl, e, sc, M, N);                                        \
         } else {                                                                                               \
             EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 2, NIMG, H * W, 0, 0, 0, 0};    \
             SBL_PREC_LAUNCH(SBL_KPM_F_, grid, s, al, bl, e, sc, M, N);                                        \
@@ -181,6 +215,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
         else SBL_CONV_DG_PM(64, 64);
 #undef SBL_CONV_DG_PM
 #undef SBL_KPM_T_
+#undef SBL_KPM_A_
 #undef SBL_KPM_F_
         SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(pm)");
         return 0;
@@ -189,11 +224,19 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     do {                                                                                                      \
         ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
         DenseKC<BN, true> bl{wt, (long)K, N};                                                                 \
-        if (bs.sums) {                                                                                        \
-            EpiStore<0, true> e{dx, (long)N, nullptr, 0, bs.sums, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, bs.y, bs.x, bs.mean, bs.inv}; \
-            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+        if (f.sums) {                                                                                         \
+            EpiStore<0, true, true> e{dx, (long)N, nullptr, 0, f.sums, nullptr, 0, 0, 0, 0, 0, 0, 0, 0,       \
+                                      f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2, f.addend, 0L};          \
+            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, true, true>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
                 SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};              \
-                sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+                sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, true, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
+            }                                                                                                 \
+        } else if (f.addend) {                                                                                \
+            EpiStore<0, false, true> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0,     \
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f.addend, 0L}; \
+            if (!(g_tailsplit && sbl_launch_gemm_tailsplit<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false, true>, BM, BN, 1>(al, bl, e, M, N, K, s, SBL_KID_CONV_DGRAD, ws, ws_bytes, SBL_CONV_WS_COUNTERS))) { \
+                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};              \
+                sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKC<BN, true>, EpiStore<0, false, true>, BM, BN, 1, WN>(al, bl, e, M, N, K, 1, s, sc); \
             }                                                                                                 \
         } else {                                                                                              \
             EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0};                               \
@@ -205,17 +248,17 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     } while (0)
     constexpr int q128 = 1;
     const bool waste128 = q128 && N >= 128 && t128 >= 512 && t128 < 1024 && (double)(sbl_cdiv(t128, 256) * 256) / (double)t128 > 1.25;
-    if (N >= 128 && t128 >= 512 && !waste128) SBL_CONV_DG(128, 128, 2);
-    else if ((N < 128 || waste128) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG(128, 64, 2);
+    if (N >= 128 && t128 >= 512 && !waste128 && !f.sums) SBL_CONV_DG(128, 128, 2);
+    else if ((N < 128 || waste128 || f.sums) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DG(128, 64, 2);
     else SBL_CONV_DG(64, 64, 2);
 #undef SBL_CONV_DG
     SBL_LAUNCH_CHECK("sbl_conv2d_dgrad");
     return 0;
 }
+static const DgradFuse kNoFuse{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                                 int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream) {
-    return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
-                             DgradBnStats{nullptr, nullptr, nullptr, nullptr, nullptr});
+    return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream, kNoFuse, 0);
 }
 extern "C" int sbl_conv2d_dgrad_bnstats(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                                         int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* act,
@@ -223,7 +266,19 @@ extern "C" int sbl_conv2d_dgrad_bnstats(const float* dy, const float* wt, float*
                                         sbl_stream_t stream) {
     SBL_REQUIRE(act && pre && mean && invstd && sums, "sbl_conv2d_dgrad_bnstats: null statistics operand");
     return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
-                             DgradBnStats{act, pre, mean, invstd, sums});
+                             DgradFuse{nullptr, 0, act, pre, mean, invstd, nullptr, nullptr, nullptr, sums}, 0);
+}
+extern "C" int sbl_conv2d_dgrad_fused(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
+                                      int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* addend,
+                                      const float* act, const float* pre, const float* mean, const float* invstd,
+                                      const float* pre2, const float* mean2, const float* invstd2, double* sums,
+                                      sbl_stream_t stream) {
+    return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
+                             DgradFuse{addend, addend && stride == 2, act, pre, mean, invstd, pre2, mean2, invstd2, sums}, 0);
+}
+extern "C" int sbl_conv1x1s2_dgrad_compact(const float* dy, const float* wt, float* dx_compact, int NIMG, int H, int W, int Cin,
+                                           int Cout, void* ws, long ws_bytes, sbl_stream_t stream) {
+    return conv2d_dgrad_impl(dy, wt, dx_compact, NIMG, H, W, Cin, Cout, 1, 1, 2, 0, ws, ws_bytes, stream, kNoFuse, 1);
 }
 
 extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int NIMG, int H, int W, int Cin, int Cout,

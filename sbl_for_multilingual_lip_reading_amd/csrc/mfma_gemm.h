@@ -24,9 +24,12 @@
 // ------------------------------------------------------------------ epilogues
 // MODE 0: C = acc (+bias) (ReLU)   MODE 1: C += acc (non-atomic; one block per tile)
 // MODE 2: atomicAdd(C, acc) (split-K; C pre-zeroed or accumulating)
-template <int MODE, bool STATS>
+// FUSE: the residual addend and the second BatchNorm of a BasicBlock's backward (fields add_src / bs_x2 below) are compiled in
+// only for the input-gradient launches that use them; the other instantiations keep their register budget.
+template <int MODE, bool STATS, bool FUSE = false>
 struct EpiStore {
     static constexpr bool kStats = STATS;
+    static constexpr bool kFuse = FUSE;
     float* C;
     long ldc;
     const float* bias;   // [N] or nullptr
@@ -45,6 +48,17 @@ struct EpiStore {
     const float* bs_x;
     const float* bs_mean;
     const float* bs_inv;
+    // a second BatchNorm fed by the same activation (the 1x1 downsample branch of a BasicBlock, video_frontend.py:69-71):
+    // stats[2N..4N) = (sum g, sum g * xhat2), so both reductions of that block ride on one epilogue
+    const float* bs_x2;
+    const float* bs_mean2;
+    const float* bs_inv2;
+    // addend: v += add_src[...] before the store and the sums - the residual branch's gradient joins the input gradient
+    // of conv1 here instead of in an autograd add.  add_ld == 0: laid out like C (same offset); else row m of the GEMM is
+    // row m of a compact (M x N, row stride add_ld) buffer (the 1x1 / stride-2 downsample's gradient lives on the
+    // even/even pixels only, i.e. on the rows of parity class (0,0)).
+    const float* add_src;
+    long add_ld;
     __device__ __forceinline__ long row_off(int m) const {
         if (!cmap) return (long)m * ldc;
         if (cmap == 2) {
@@ -57,22 +71,30 @@ struct EpiStore {
         return (((long)img * cH + 2 * a + cph) * cW + 2 * b + cpw) * ldc;
     }
     __device__ __forceinline__ void tile(const f32x16& a, int mbase, int n, int M, int N, int lane,
-                                         float& s1, float& s2) const {
+                                         float& s1, float& s2, float& s3) const {
         if (n >= N) return;
         const float b = bias ? bias[n] : 0.f;
-        float bmu = 0.f, bis = 0.f;
+        float bmu = 0.f, bis = 0.f, bmu2 = 0.f, bis2 = 0.f;
         if (STATS && bs_y) {
             bmu = bs_mean[n];
             bis = bs_inv[n];
+            if (FUSE && bs_x2) {
+                bmu2 = bs_mean2[n];
+                bis2 = bs_inv2[n];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            // (the fused form reads up to four more tensors per element: without a fence per row the scheduler hoists all the
+            // loads of a tile - 256 VGPRs, one wave per SIMD on the 128x128 tiles)
+            if (FUSE) __builtin_amdgcn_sched_barrier(0);
             const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m < M) {
                 float v = a[r] + b;
                 if (relu) v = fmaxf(v, 0.f);
                 if (relu_mask) v = relu_mask[(long)m * ldm + n] > 0.f ? v : 0.f;
                 const long o = row_off(m) + n;
+                if (FUSE && add_src) v += add_ld ? add_src[(long)m * add_ld + n] : add_src[o];
                 float* q = C + o;
                 if (MODE == 0) *q = v;
                 else if (MODE == 1) *q += v;
@@ -82,6 +104,7 @@ struct EpiStore {
                         const float g = bs_y[o] > 0.f ? v : 0.f;
                         s1 += g;
                         s2 += g * ((bs_x[o] - bmu) * bis);
+                        if (FUSE && bs_x2) s3 += g * ((bs_x2[o] - bmu2) * bis2);
                     } else {
                         s1 += v;
                         s2 += v * v;
@@ -183,15 +206,22 @@ __device__ __forceinline__ void sbl_tile_finish(const AL& al, const typename AL:
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / WM) + i * 32, n, M, N, lane, s1, s2);
+        for (int i = 0; i < TM; ++i) epi.tile(acc[i][j], m0 + wm * (BM / WM) + i * 32, n, M, N, lane, s1, s2, s3);
         if (EPI::kStats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (lane < 32 && n < N) {
                 atomicAdd(epi.stats + n, (double)s1);
                 atomicAdd(epi.stats + N + n, (double)s2);
+            }
+            if (EPI::kFuse && epi.bs_x2) {      // (workgroup-uniform)
+                s3 += __shfl_xor(s3, 32, 64);
+                if (lane < 32 && n < N) {
+                    atomicAdd(epi.stats + 2 * N + n, (double)s1);
+                    atomicAdd(epi.stats + 3 * N + n, (double)s3);
+                }
             }
         }
     }

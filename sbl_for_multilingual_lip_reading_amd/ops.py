@@ -1009,7 +1009,7 @@ class ConvBNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, relu, stride, training, momentum, eps, box_out=None,
-                box_in=None, nbt=None):
+                box_in=None, nbt=None, ctl=None):
         """box_out / box_in (dicts or None) link conv1 -> bn1 -> relu to the conv2 that consumes it (BasicBlock,
         video_frontend.py:31-35): this node publishes (pre-BN output, mean, invstd) in box_out; the consumer, given the same
         dict as box_in, computes bn1's backward reduction in the epilogue of its input-gradient convolution
@@ -1048,6 +1048,16 @@ class ConvBNFn(torch.autograd.Function):
         ctx.cfg = (relu, stride, pad, training, res is not None)
         ctx.gb_bn = (_gbuf(gamma), _gbuf(beta))
         ctx.box_out = ctx.box_in = None
+        # ctl (BasicBlock, video_frontend.py:28-41) = {"role": "conv1" | "ds" | "conv2", "link": dict shared by the block's
+        # three nodes, "prev": the dict the PREVIOUS block published on its output tensor, "pub": the dict this block
+        # publishes}.  It lets backward (a) fold the residual branch's gradient into conv1's input-gradient epilogue instead
+        # of an autograd add, and (b) reduce the previous block's bn2 (+ downsample BN) backward sums in that same epilogue.
+        ctx.ctl = ctl if training else None
+        if ctx.ctl is not None:
+            if ctl["role"] == "conv2":
+                ctl["pub"].update(conv=conv, mean=mean, invstd=invstd, act=y)
+            elif ctl["role"] == "ds":
+                ctl["pub"].update(conv2=conv, mean2=mean, invstd2=invstd)
         if training:      # (grad mode is off inside Function.forward; backward only runs if a tape exists)
             if box_out is not None and relu and res is None:
                 box_out.update(conv=conv, mean=mean, invstd=invstd, act=y)
@@ -1068,9 +1078,20 @@ class ConvBNFn(torch.autograd.Function):
         dy = dy.contiguous()
         rows = conv.numel() // Cout
         box = ctx.box_out
+        ctl = ctx.ctl
+        role = ctl["role"] if ctl is not None else None
+        pub = ctl["pub"] if role in ("conv2", "ds") else None
         if box is not None and box.get("sums") is not None and box.get("dx_ptr") == dy.data_ptr():
             sums = box.pop("sums")           # reduced in the epilogue of the consumer's input-gradient convolution
             box.clear()
+        elif role == "conv2" and pub.get("sums") is not None and pub.get("dx_ptr") == dy.data_ptr():
+            # the NEXT block's conv1 input-gradient epilogue reduced them (dy is that convolution's output, residual included)
+            full = pub.pop("sums")
+            sums = full[:2 * Cout]
+            if full.numel() == 4 * Cout:
+                ctl["link"]["ds_sums"] = full[2 * Cout:]     # the downsample BatchNorm's pair: same g, its own xhat
+        elif role == "ds" and ctl["link"].get("ds_sums") is not None:
+            sums = ctl["link"].pop("ds_sums")
         else:
             sums = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
             call("sbl_bn_bwd_reduce", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(sums), rows, Cout, int(relu),
@@ -1086,15 +1107,47 @@ class ConvBNFn(torch.autograd.Function):
             dbeta = torch.empty(Cout, device=dev, dtype=torch.float32)
             call("sbl_bn_bwd_apply", _p(dy), _p(y), _p(conv), _p(mean), _p(invstd), _p(gamma), _p(sums), _p(dconv), _p(dres),
                  _p(dgamma), _p(dbeta), rows, Cout, int(relu), 0, _s())
+        dres_ret = dres
+        if role == "conv2" and ctl["link"].get("identity"):
+            ctl["link"]["dres"] = dres        # conv1's input-gradient epilogue adds it (conv1's backward runs after this one)
+            dres_ret = None
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and role == "ds" and not ctl["link"].get("main_done"):
+            # 1x1 / stride-2: the gradient lives on the even/even pixels; hand the compact form to conv1's epilogue (this node
+            # was created after conv1, so the engine runs it first) instead of a zero-filled full-size tensor + autograd add
+            if w_dg is None:
+                w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+                w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
+                call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, None, 0, _s())
+            dxc = torch.empty(NIMG, (H + 1) // 2, (W + 1) // 2, Cin, device=dev, dtype=torch.float32)
+            call("sbl_conv1x1s2_dgrad_compact", _p(dconv), _p(w_dg), _p(dxc), NIMG, H, W, Cin, Cout, _workspace().data_ptr(), WS_BYTES, _s())
+            ctl["link"]["dx_ds"] = dxc
+        elif ctx.needs_input_grad[0]:
             if w_dg is None:
                 w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
                 w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32)
                 call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, None, 0, _s())
             dx = torch.empty_like(x)
             bi = ctx.box_in
-            if bi is not None and bi.get("conv") is not None:
+            if role == "conv1":
+                link = ctl["link"]
+                addend = link.pop("dres", None) if link.get("identity") else link.pop("dx_ds", None)
+                link["main_done"] = True
+                prev = ctl.get("prev")
+                fuse = (prev is not None and addend is not None and prev.get("act") is not None
+                        and prev["act"].data_ptr() == x.data_ptr())
+                nsums = None
+                if fuse:
+                    two = prev.get("conv2") is not None
+                    nsums = torch.empty((4 if two else 2) * Cin, device=dev, dtype=torch.float64)
+                    call("sbl_conv2d_dgrad_fused", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                         _workspace().data_ptr(), WS_BYTES, _p(addend), _p(x), _p(prev["conv"]), _p(prev["mean"]), _p(prev["invstd"]),
+                         _p(prev.get("conv2")), _p(prev.get("mean2")), _p(prev.get("invstd2")), _p(nsums), _s())
+                    prev["sums"], prev["dx_ptr"] = nsums, dx.data_ptr()
+                else:
+                    call("sbl_conv2d_dgrad_fused", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
+                         _workspace().data_ptr(), WS_BYTES, _p(addend), None, None, None, None, None, None, None, None, _s())
+            elif bi is not None and bi.get("conv") is not None:
                 nsums = torch.empty(2 * Cin, device=dev, dtype=torch.float64)
                 call("sbl_conv2d_dgrad_bnstats", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                      _workspace().data_ptr(), WS_BYTES, _p(x), _p(bi["conv"]), _p(bi["mean"]), _p(bi["invstd"]), _p(nsums), _s())
@@ -1117,15 +1170,15 @@ class ConvBNFn(torch.autograd.Function):
             x.record_stream(side)
             dconv.record_stream(side)
             _arm_side_join()
-            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+            return dx, None, dgamma, dbeta, None, None, dres_ret, None, None, None, None, None, None, None, None, None
         dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
         if gw is not None:
             call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
-            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+            return dx, None, dgamma, dbeta, None, None, dres_ret, None, None, None, None, None, None, None, None, None
         dw = torch.empty_like(w)
         call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(dw), Cout, Cin, KH, KW, 0, _s())
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres_ret, None, None, None, None, None, None, None, None, None
 
 
 class AvgPoolFn(torch.autograd.Function):

@@ -17,11 +17,11 @@ def conv3x3(in_planes, out_planes, stride=1):
                      padding=1, bias=False)
 
 
-def _conv_bn(x, conv, bn, res, relu, training, box_out=None, box_in=None):
+def _conv_bn(x, conv, bn, res, relu, training, box_out=None, box_in=None, ctl=None):
     """conv -> BatchNorm2d -> (+res) -> (ReLU), NHWC, one tape node; BN side effects like nn.BatchNorm2d."""
     return ops.ConvBNFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu,
                               conv.stride[0], training, bn.momentum, bn.eps, box_out, box_in,
-                              bn.num_batches_tracked if training else None)      # (+= 1 inside the finalize kernel)
+                              bn.num_batches_tracked if training else None, ctl)      # (+= 1 inside the finalize kernel)
 
 
 class BasicBlock(nn.Module):
@@ -40,12 +40,22 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         # video_frontend.py:28-41 on NHWC activations
         box = {}      # lets conv2's backward do bn1's reduction pass in its epilogue (ops.ConvBNFn)
-        out = _conv_bn(x, self.conv1, self.bn1, None, True, self.training, box_out=box)
+        # link: shared by this block's tape nodes; prev / pub: what the previous block published on its output tensor and
+        # what this one publishes on its own (ops.ConvBNFn: residual gradient and the BatchNorm backward sums of the
+        # previous block ride on conv1's input-gradient epilogue)
+        link = {"identity": self.downsample is None}
+        prev, pub = getattr(x, "_sbl_pub", None), {}
+        out = _conv_bn(x, self.conv1, self.bn1, None, True, self.training, box_out=box,
+                       ctl={"role": "conv1", "link": link, "prev": prev})
         if self.downsample is not None:
-            residual = _conv_bn(x, self.downsample[0], self.downsample[1], None, False, self.training)
+            residual = _conv_bn(x, self.downsample[0], self.downsample[1], None, False, self.training,
+                                ctl={"role": "ds", "link": link, "pub": pub})
         else:
             residual = x
-        return _conv_bn(out, self.conv2, self.bn2, residual, True, self.training, box_in=box)
+        y = _conv_bn(out, self.conv2, self.bn2, residual, True, self.training, box_in=box,
+                     ctl={"role": "conv2", "link": link, "pub": pub})
+        y._sbl_pub = pub
+        return y
 
 
 class ResNet(nn.Module):
