@@ -1264,3 +1264,90 @@ def test_full_size_step_properties(ops):
     assert abs(l3 - l1) < 1e-5          # BN statistics are reduced with atomics: the forward repeats to a few ulp
     assert rel(g3, 2 * g1, "decoder.") < 1e-5 and rel(g3, 2 * g1, "encoder.") < 1e-4 and rel(g3, 2 * g1, "visual_frontend.") < 2e-2
     assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+
+
+# --------------------------------------------------------------------------- BASELINE config 5: mixed bf16
+def test_config5_mixed_bf16_vs_fp32_oracle():
+    """The opt-in "bf16" matrix mode (bf16 MFMA inputs, fp32 master weights, fp32 accumulation and fp32 everything else:
+    BASELINE config 5) against the fp32 CPU oracle at config-5 geometry, B = 2, 1+1 layers.  Documented tolerance of this
+    mode (NOT the parity path - that is "f32" / "bf16x6" above): logits within 5e-2 absolute (bf16 has 8 significand bits:
+    measured 1-2e-2 through 18 convolutions + 2 transformer layers), loss within 2e-2, transformer gradients within 5e-2
+    in relative L2 per tensor."""
+    from oracle import sbl_oracle as O
+    from sbl_for_multilingual_lip_reading_amd import _lib, ops
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    _lib.load()
+    B, T, H, W, ne, nd = 2, 64, 112, 112, 1, 1
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 23)
+    sd = O.make_state_dict(ne, nd, requires_grad=True)
+    random.seed(9)
+    coins = O.draw_coins()
+    ref = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins, ne, nd)
+    rloss = O.train_step_loss(ref)
+    rloss.backward()
+    ops.set_matmul_precision("bf16")
+    try:
+        m = build_model(ne, nd).train()
+        random.seed(9)
+        pl, gl, pr, gr = m(torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV))
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_matmul_precision("f32")
+    d = max(maxdiff(pl, ref["pred_l2r"]), maxdiff(pr, ref["pred_r2l"]))
+    assert 1e-5 < d < 5e-2, d                     # really ran in bf16 (fp32 lands at 1e-5), and within the mode's bound
+    assert abs(loss.item() - rloss.item()) < 2e-2
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if (n.startswith("decoder") or n.startswith("encoder")) and not n.endswith("w_ks.bias") and p.dim() >= 2:
+            r = sd[n].grad
+            worst = max(worst, float((p.grad.detach().cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30)))
+    assert worst < 5e-2, worst
+
+
+def test_config5_full_size_bf16_properties():
+    """BASELINE config 5 at full size (B = 16 clips per GPU, T = 64, 112x112, 6+6 layers, dropout off): the mixed-bf16 step
+    against the fp32-grade split-bf16 x6 step of the same weights and inputs (the CPU oracle needs minutes here): same
+    greedy choices wherever the fp32 argmax margin is not tiny, loss within 2e-2, logits within 1e-1, every gradient
+    finite, decoder / encoder gradients within 1e-1 in relative L2 per segment; and the bf16 backward is linear in the
+    loss scale to fp32 rounding (same masks, same tokens)."""
+    from sbl_for_multilingual_lip_reading_amd import _lib, dp, ops
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    _lib.load()
+    m = build_model(6, 6).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    flat = dp.FlatModel(m)
+    x, l2r, r2l = detfill.synthetic_batch(16, 64, 112, 112, 7)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    m.decoder.coins_host = [False] * 16            # teacher forcing throughout: both modes decode the same tokens
+
+    def run(mode, scale=1.0):
+        ops.set_matmul_precision(mode)
+        try:
+            flat.zero_grad()
+            pl, gl, pr, gr = m(xd, ld, rd)
+            loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+            (loss * scale).backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_matmul_precision("f32")
+        return float(loss), flat.flat_grad.clone(), pl.detach().clone()
+
+    def rel(a, b, seg):
+        lo, hi = flat.span(seg)
+        return float((a[lo:hi] - b[lo:hi]).norm() / b[lo:hi].norm())
+
+    l6, g6, p6 = run("bf16x6")
+    l1, g1, p1 = run("bf16")
+    assert abs(l1 - l6) < 2e-2 and maxdiff(p1, p6) < 1e-1
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    assert rel(g1, g6, "decoder.") < 1e-1 and rel(g1, g6, "encoder.") < 1e-1
+    top2 = p6.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 0.2
+    assert bool((p1.argmax(-1) == p6.argmax(-1))[clear].all())
+    l2, g2, _ = run("bf16", scale=2.0)
+    assert abs(l2 - l1) < 1e-4 and rel(g2, 2 * g1, "decoder.") < 1e-4 and rel(g2, 2 * g1, "encoder.") < 1e-3
