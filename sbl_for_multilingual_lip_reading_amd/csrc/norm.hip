@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void add_layernorm2_fwd_kernel(LnFwdSet a0, Ln
 
 // dz = rstd*(gamma*dy - mean(gamma*dy) - xhat*mean(gamma*dy*xhat)); dgamma += dy*xhat, dbeta += dy (column sums:
 // each wave walks its rows keeping 8 per-lane partials, LDS-combined per block, then float atomics)
-#define SBL_LN_BWD_WAVES 16      // 1024-thread workgroups: 16 waves x RW rows in flight per workgroup
+#define SBL_LN_BWD_WAVES 8       // 512-thread workgroups: 8 waves x RW rows in flight per workgroup
 __global__ __launch_bounds__(64 * SBL_LN_BWD_WAVES) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ res, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(64 * SBL_LN_BWD_WAVES) void add_layernorm_bwd_kerne
         red[wave][1][c] = db[k];
     }
     __syncthreads();
-    {   // 1024 threads = the 2 x 512 column sums: one float atomic each
-        const int which = threadIdx.x >> 9, c = threadIdx.x & 511;
+    for (int i = threadIdx.x; i < 1024; i += 64 * SBL_LN_BWD_WAVES) {      // the 2 x 512 column sums: one float atomic each
+        const int which = i >> 9, c = i & 511;
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < SBL_LN_BWD_WAVES; ++w) t += red[w][which][c];
@@ -502,12 +502,14 @@ extern "C" int sbl_add_layernorm_bwd(const float* dy, const float* x, const floa
     SBL_REQUIRE(D == 512, "sbl_add_layernorm_bwd: D=%d", D);
     SBL_REQUIRE(dy && x && gamma && mean && rstd && dz && dgamma && dbeta && M > 0, "sbl_add_layernorm_bwd: bad args");
     SBL_REQUIRE(sbl_aligned16(dy) && sbl_aligned16(x) && sbl_aligned16(dz) && (!res || sbl_aligned16(res)) && sbl_aligned16(gamma), "sbl_add_layernorm_bwd: unaligned");
-    // few, fat workgroups (each ends with 1024 float atomics on the same dgamma / dbeta words) of 16 waves: 32 rows in
-    // flight per workgroup, ~136 workgroups at the stage-batched decoder's 4352 rows.  (256-thread workgroups capped at
-    // 128 kept 364 waves in flight on the whole chip: 28.6 us per launch, 1.6 TB/s.)
+    // few, fat workgroups (each ends with 1024 float atomics on the same dgamma / dbeta words) of 8 waves: 16 rows in
+    // flight per workgroup, two trips each at the stage-batched decoder's 4352 rows (136 workgroups).  256-thread
+    // workgroups capped at 128 kept 364 waves in flight on the whole chip (28.6 us per launch in the step); 1024-thread
+    // ones do not fit beside the other stream's GEMM workgroups (6 x 4 waves per CU) and wait for a CU to drain (58.8 us).
     constexpr int rows_trip = SBL_LN_BWD_WAVES * 2;
-    int blocks = sbl_cdiv(M, rows_trip);
+    int blocks = sbl_cdiv(M, 2 * rows_trip);
     if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
     const int rpb = sbl_cdiv(sbl_cdiv(M, blocks), rows_trip) * rows_trip;
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(sbl_cdiv(M, rpb)), dim3(64 * SBL_LN_BWD_WAVES), 0, (hipStream_t)stream, dy, x, res,
                        gamma, mean, rstd, dz, dx_drop, dgamma, dbeta, M, rpb, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
