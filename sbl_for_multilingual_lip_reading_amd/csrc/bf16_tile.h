@@ -153,31 +153,8 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-        al.load(sa, kbeg + u * SBL_BK, kend, ra[u]);
-        bl.load(sb, kbeg + u * SBL_BK, kend, rb[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-        if (do_colsum) al.accum(ra[u], cs);
-        bf_store<AL, BM, NPL>(smem + u * A_SLAB, ra[u], tid);
-        bf_store<BL, BN, NPL>(smem + A_BUF + u * B_SLAB, rb[u], tid);
-    }
-    __syncthreads();
-
     const int arow = wm * (BM / WM), brow = wn * (BN / WN);
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += MK) {
-        const bool has_next = (k0 + MK) < kend;
-        if (has_next) {
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                al.load(sa, k0 + MK + u * SBL_BK, kend, ra[u]);
-                bl.load(sb, k0 + MK + u * SBL_BK, kend, rb[u]);
-            }
-        }
-        const unsigned char* base = smem + cur * BUF;
+    auto compute = [&](const unsigned char* base) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             bf16x8 a[NPL][TM], b[NPL][TN];
@@ -196,17 +173,78 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
                     for (int t = 0; t < T::N; ++t)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[T::pa(t)][i], b[T::pb(t)][j], acc[i][j], 0, 0, 0);
         }
-        if (has_next) {
-            unsigned char* nb = smem + (cur ^ 1) * BUF;
+    };
+    // 64x64 tiles (one accumulator per wave, 8 staging registers per slab): a ring of RD register sets keeps the global loads
+    // of RD slabs in flight.  These launches have one or two workgroups per CU (544 tiles of a 4352x512 product on 256 CUs)
+    // and 6 MFMAs per slab: nothing else hides a load round trip.  Loads past the end of K are issued anyway (out-of-range
+    // offset: zeros, no memory access) and their zeros stored to the idle LDS buffer, so the loop body has no branch and the
+    // compiler keeps counted vmcnt waits.  Larger tiles keep one set: a second one costs them a wave per SIMD.
+    constexpr int RD = (KU == 1 && TM * TN == 1) ? 4 : 1;
+    if constexpr (RD > 1) {
+        typename AL::Regs qa[RD];
+        typename BL::Regs qb[RD];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                if (do_colsum) al.accum(ra[u], cs);
-                bf_store<AL, BM, NPL>(nb + u * A_SLAB, ra[u], tid);
-                bf_store<BL, BN, NPL>(nb + A_BUF + u * B_SLAB, rb[u], tid);
+        for (int q = 0; q < RD; ++q) {
+            al.load(sa, kbeg + q * SBL_BK, kend, qa[q]);
+            bl.load(sb, kbeg + q * SBL_BK, kend, qb[q]);
+        }
+        if (do_colsum) al.accum(qa[0], cs);
+        bf_store<AL, BM, NPL>(smem, qa[0], tid);
+        bf_store<BL, BN, NPL>(smem + A_BUF, qb[0], tid);
+        al.load(sa, kbeg + RD * SBL_BK, kend, qa[0]);
+        bl.load(sb, kbeg + RD * SBL_BK, kend, qb[0]);
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += RD * SBL_BK) {
+#pragma unroll
+            for (int q = 0; q < RD; ++q) {
+                const int k = k0 + q * SBL_BK;          // slab in LDS buffer q & 1; ring slot (q + 1) % RD holds slab k + 16
+                if (k >= kend) break;
+                unsigned char* nb = smem + ((q + 1) & 1) * BUF;
+                if (do_colsum) al.accum(qa[(q + 1) % RD], cs);
+                bf_store<AL, BM, NPL>(nb, qa[(q + 1) % RD], tid);
+                bf_store<BL, BN, NPL>(nb + A_BUF, qb[(q + 1) % RD], tid);
+                al.load(sa, k + (RD + 1) * SBL_BK, kend, qa[(q + 1) % RD]);
+                bl.load(sb, k + (RD + 1) * SBL_BK, kend, qb[(q + 1) % RD]);
+                compute(smem + (q & 1) * BUF);
+                __syncthreads();
             }
         }
+    } else {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            al.load(sa, kbeg + u * SBL_BK, kend, ra[u]);
+            bl.load(sb, kbeg + u * SBL_BK, kend, rb[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            if (do_colsum) al.accum(ra[u], cs);
+            bf_store<AL, BM, NPL>(smem + u * A_SLAB, ra[u], tid);
+            bf_store<BL, BN, NPL>(smem + A_BUF + u * B_SLAB, rb[u], tid);
+        }
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += MK) {
+            const bool has_next = (k0 + MK) < kend;
+            if (has_next) {
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    al.load(sa, k0 + MK + u * SBL_BK, kend, ra[u]);
+                    bl.load(sb, k0 + MK + u * SBL_BK, kend, rb[u]);
+                }
+            }
+            compute(smem + cur * BUF);
+            if (has_next) {
+                unsigned char* nb = smem + (cur ^ 1) * BUF;
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    if (do_colsum) al.accum(ra[u], cs);
+                    bf_store<AL, BM, NPL>(nb + u * A_SLAB, ra[u], tid);
+                    bf_store<BL, BN, NPL>(nb + A_BUF + u * B_SLAB, rb[u], tid);
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     sbl_tile_finish<AL, EPI, BM, BN, WN, TM, TN>(al, sa, epi, sc, acc, cs, do_colsum, M, N, m0, n0, tile, z, nz);
 }
