@@ -49,25 +49,30 @@ struct BfImage {
     static constexpr int BYTES = KC ? BR * 32 : 16 * ROW;     // one plane of one 16-deep slab
 };
 
-__device__ __forceinline__ unsigned bf_pack2(float a, float b) {
-    bf16x2 p = {(__bf16)a, (__bf16)b};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (round to nearest even, one v_cvt_pk_bf16_f32) and back to two fp32.  The low element comes
+// back through v_perm_b32 rather than `pair << 16`: for the shift the compiler re-derives the low element with a second
+// conversion instruction (only one half of the pair is "demanded").
+__device__ __forceinline__ unsigned bf_pack2(f32x2 v) {
+    bf16x2 p = {(__bf16)v.x, (__bf16)v.y};
     return __builtin_bit_cast(unsigned, p);
 }
-__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ f32x2 bf_unpack2(unsigned u) {
+    return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_perm(u, 0u, 0x05040c0cu)), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
 
-// four consecutive fp32 values -> NPL planes of four bf16 (8 bytes each)
+// four consecutive fp32 values -> NPL planes of four bf16 (8 bytes each); 9 VALU operations per pair of values for three
+// planes (3 conversions, 2 x (shift, mask), 2 packed subtractions)
 template <int NPL>
 __device__ __forceinline__ void bf_split4(const float4& v, uint2 (&out)[NPL]) {
-    const unsigned a0 = bf_pack2(v.x, v.y), b0 = bf_pack2(v.z, v.w);
+    const f32x2 x = {v.x, v.y}, y = {v.z, v.w};
+    const unsigned a0 = bf_pack2(x), b0 = bf_pack2(y);
     out[0] = make_uint2(a0, b0);
     if constexpr (NPL > 1) {
-        const float rx = v.x - bf_lo(a0), ry = v.y - bf_hi(a0), rz = v.z - bf_lo(b0), rw = v.w - bf_hi(b0);
-        const unsigned a1 = bf_pack2(rx, ry), b1 = bf_pack2(rz, rw);
+        const f32x2 rx = x - bf_unpack2(a0), ry = y - bf_unpack2(b0);
+        const unsigned a1 = bf_pack2(rx), b1 = bf_pack2(ry);
         out[1] = make_uint2(a1, b1);
-        if constexpr (NPL > 2) {
-            out[2] = make_uint2(bf_pack2(rx - bf_lo(a1), ry - bf_hi(a1)), bf_pack2(rz - bf_lo(b1), rw - bf_hi(b1)));
-        }
+        if constexpr (NPL > 2) out[2] = make_uint2(bf_pack2(rx - bf_unpack2(a1)), bf_pack2(ry - bf_unpack2(b1)));
     }
 }
 
@@ -118,6 +123,12 @@ __device__ __forceinline__ bf16x8 bf_frag(const unsigned char* img, int rb, int 
     }
 }
 
+// SBL_ABL (tools/probes/tile_ablate.hip only; never set in the library build): bit 0 drops the MFMAs, bit 1 the LDS fragment
+// reads, bit 2 the split + LDS stores, bit 3 the global loads of the K loop - what each stage costs is the time that goes
+// away with it.
+#ifndef SBL_ABL
+#define SBL_ABL 0
+#endif
 template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int NT>
 __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
                                                  int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
@@ -129,9 +140,10 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
     constexpr int A_SLAB = NPL * IA::BYTES, B_SLAB = NPL * IB::BYTES;
     constexpr int A_BUF = KU * A_SLAB, BUF = KU * (A_SLAB + B_SLAB);
     constexpr int MK = KU * SBL_BK;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
     constexpr int WM = 4 / WN;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int RD = KU != 1 ? 1 : (TM * TN == 1 ? 4 : 2);      // register ring depth (below)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     sbl_stamp_begin(sc.stamp);
@@ -161,26 +173,36 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[pl][i] = bf_frag<BM, AL::kKC>(base + u * A_SLAB + pl * IA::BYTES, arow + i * 32, lane);
+                for (int i = 0; i < TM; ++i) {
+                    if (SBL_ABL & 2) { for (int e = 0; e < 8; ++e) a[pl][i][e] = (__bf16)(float)(lane + e); }
+                    else a[pl][i] = bf_frag<BM, AL::kKC>(base + u * A_SLAB + pl * IA::BYTES, arow + i * 32, lane);
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[pl][j] = bf_frag<BN, BL::kKC>(base + A_BUF + u * B_SLAB + pl * IB::BYTES, brow + j * 32, lane);
+                for (int j = 0; j < TN; ++j) {
+                    if (SBL_ABL & 2) { for (int e = 0; e < 8; ++e) b[pl][j][e] = (__bf16)(float)(lane - e); }
+                    else b[pl][j] = bf_frag<BN, BL::kKC>(base + A_BUF + u * B_SLAB + pl * IB::BYTES, brow + j * 32, lane);
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int t = 0; t < T::N; ++t)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[T::pa(t)][i], b[T::pb(t)][j], acc[i][j], 0, 0, 0);
+                    for (int t = 0; t < T::N; ++t) {
+                        if (SBL_ABL & 1) asm volatile("" ::"v"(a[T::pa(t)][i]), "v"(b[T::pb(t)][j]));
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[T::pa(t)][i], b[T::pb(t)][j], acc[i][j], 0, 0, 0);
+                    }
         }
     };
-    // 64x64 tiles (one accumulator per wave, 8 staging registers per slab): a ring of RD register sets keeps the global loads
-    // of RD slabs in flight.  These launches have one or two workgroups per CU (544 tiles of a 4352x512 product on 256 CUs)
-    // and 6 MFMAs per slab: nothing else hides a load round trip.  Loads past the end of K are issued anyway (out-of-range
-    // offset: zeros, no memory access) and their zeros stored to the idle LDS buffer, so the loop body has no branch and the
-    // compiler keeps counted vmcnt waits.  Larger tiles keep one set: a second one costs them a wave per SIMD.
-    constexpr int RD = (KU == 1 && TM * TN == 1) ? 4 : 1;
-    if constexpr (RD > 1) {
+    // Register rings keep the global loads of several slabs in flight; loads past the end of K are issued anyway (out-of-range
+    // offset: zeros, no memory access), so the loop bodies have no branch around a load and the compiler keeps counted
+    // vmcnt waits.
+    //  * 64x64 tiles (one accumulator per wave, 8 staging registers per slab; one or two workgroups per CU on the
+    //    4352-row products, 6 MFMAs per slab): four sets - nothing else hides a load round trip.  (Two slabs per LDS buffer
+    //    and per barrier were measured too: 48 KB of LDS per workgroup costs more residency than the barriers cost.)
+    //  * larger tiles: two sets, one slab per barrier, and the split of the next slab (VALU) spread through the shadows of
+    //    this slab's MFMAs with scheduling-group barriers.
+    if constexpr (RD == 4) {
         typename AL::Regs qa[RD];
         typename BL::Regs qb[RD];
 #pragma unroll
@@ -201,11 +223,53 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
                 if (k >= kend) break;
                 unsigned char* nb = smem + ((q + 1) & 1) * BUF;
                 if (do_colsum) al.accum(qa[(q + 1) % RD], cs);
-                bf_store<AL, BM, NPL>(nb, qa[(q + 1) % RD], tid);
-                bf_store<BL, BN, NPL>(nb + A_BUF, qb[(q + 1) % RD], tid);
-                al.load(sa, k + (RD + 1) * SBL_BK, kend, qa[(q + 1) % RD]);
-                bl.load(sb, k + (RD + 1) * SBL_BK, kend, qb[(q + 1) % RD]);
+                if (!(SBL_ABL & 4)) {
+                    bf_store<AL, BM, NPL>(nb, qa[(q + 1) % RD], tid);
+                    bf_store<BL, BN, NPL>(nb + A_BUF, qb[(q + 1) % RD], tid);
+                } else {
+                    const float4 ka = qa[(q + 1) % RD].v[0], kb = qb[(q + 1) % RD].v[0];
+                    asm volatile("" ::"v"(ka.x), "v"(ka.y), "v"(ka.z), "v"(ka.w), "v"(kb.x), "v"(kb.y), "v"(kb.z), "v"(kb.w));
+                }
+                if (!(SBL_ABL & 8)) {
+                    al.load(sa, k + (RD + 1) * SBL_BK, kend, qa[(q + 1) % RD]);
+                    bl.load(sb, k + (RD + 1) * SBL_BK, kend, qb[(q + 1) % RD]);
+                }
                 compute(smem + (q & 1) * BUF);
+                __syncthreads();
+            }
+        }
+    } else if constexpr (RD == 2) {
+        typename AL::Regs qa[RD];
+        typename BL::Regs qb[RD];
+#pragma unroll
+        for (int q = 0; q < RD; ++q) {
+            al.load(sa, kbeg + q * SBL_BK, kend, qa[q]);
+            bl.load(sb, kbeg + q * SBL_BK, kend, qb[q]);
+        }
+        if (do_colsum) al.accum(qa[0], cs);
+        bf_store<AL, BM, NPL>(smem, qa[0], tid);
+        bf_store<BL, BN, NPL>(smem + A_BUF, qb[0], tid);
+        al.load(sa, kbeg + RD * SBL_BK, kend, qa[0]);
+        bl.load(sb, kbeg + RD * SBL_BK, kend, qb[0]);
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += RD * SBL_BK) {
+#pragma unroll
+            for (int q = 0; q < RD; ++q) {          // an odd slab count runs one slab of zeros: no branch inside the body
+                const int k = k0 + q * SBL_BK;      // slab in LDS buffer q; ring slot q ^ 1 holds slab k + 16
+                unsigned char* nb = smem + (q ^ 1) * BUF;
+                if (do_colsum) al.accum(qa[q ^ 1], cs);
+                bf_store<AL, BM, NPL>(nb, qa[q ^ 1], tid);
+                bf_store<BL, BN, NPL>(nb + A_BUF, qb[q ^ 1], tid);
+                al.load(sa, k + (RD + 1) * SBL_BK, kend, qa[q ^ 1]);
+                bl.load(sb, k + (RD + 1) * SBL_BK, kend, qb[q ^ 1]);
+                compute(smem + q * BUF);
+                constexpr int NM = TM * TN * T::N;
+                constexpr int NV = (2 * NPL * ((BM + BN) * SBL_BK / 256) + 12 + NM - 1) / NM;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+                }
                 __syncthreads();
             }
         }

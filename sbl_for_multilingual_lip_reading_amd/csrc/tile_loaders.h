@@ -320,7 +320,10 @@ static inline FastDiv sbl_fastdiv(unsigned d) {
     f.s = l - 1;
     return f;
 }
-__device__ __forceinline__ unsigned sbl_div(unsigned n, const FastDiv& f) { return f.s < 0 ? n : (__umulhi(n, f.m) >> f.s); }
+__device__ __forceinline__ unsigned sbl_div(unsigned n, const FastDiv& f) {
+    const unsigned q = __umulhi(n, f.m) >> (f.s & 31);      // always computed: a select, not a branch, in the K loops
+    return f.s < 0 ? n : q;
+}
 
 struct ConvGeom {
     int NIMG, OH, OW;   // GEMM-row grid
