@@ -57,7 +57,7 @@ KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW,
                 5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
                 6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)",
                 7: "sbl_wgrad_group_kernel<SegMC,SegMC 128x128> (all deferred decoder / encoder weight grads, one launch each, no split-K)",
-                8: "stem (Conv3d 5x7x7 fwd + BN/ReLU/pool + backward reduce + weight gradient; fp32 MFMA in every mode)",
+                8: "stem (Conv3d 5x7x7 fwd + BN/ReLU/pool + backward reduce + weight gradient; the two contractions follow the matmul precision)",
                 9: "attention_fwd/bwd_kernel (encoder self-attention and long cross-attention, one workgroup per (batch, head); fp32 MFMA)"}
 # kernel-name patterns of each family in the rocprofv3 --pmc summary (profiles/*_pmc_fetch_write_per_kernel.csv)
 KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm2?_kernel<Dense[KM]C<64, \w+>, Dense[KM]C<64, \w+>, EpiStore",
@@ -588,8 +588,8 @@ def main():
                 e = {"kid": kid, "bytes": f["bytes"], "kernel": KERNEL_NAMES.get(kid, str(kid)), "launches_per_step": f["launches"],
                      "ms_per_step": round(f["us"] / 1e3, 3), "avg_launch_us": round(f["us"] / f["launches"], 2),
                      "achieved_TFLOPs": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
-                if kid in (8, 9):      # fp32 MFMA kernels in every mode; the stem is also judged against HBM
-                    e["frac"] = e["frac_of_fp32_mfma_peak"]
+                if kid in (8, 9):      # the stem is also judged against HBM; attention is fp32 MFMA in every mode
+                    e["frac"] = e["frac_of_fp32_mfma_peak"] if kid == 9 else round(tf / peak, 4)
                     e["achieved_TBs"] = round(f["bytes"] / (f["us"] * 1e-6) / 1e12, 3)
                     e["frac_of_hbm_peak"] = round(e["achieved_TBs"] / HBM_PEAK_TBS, 4)
                 else:

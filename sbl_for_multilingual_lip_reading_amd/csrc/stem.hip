@@ -9,6 +9,8 @@
 // two passes too: a reduction for the BN adjoint, then a weight-gradient GEMM whose A operand (dconv) is
 // recomputed on the fly from conv_out, the pooled gradient and the argmax — dconv is never materialised.
 #include "sbl_common.h"
+#include "bf16_split.h"
+extern int g_sbl_prec;      // gemm.hip: 0 = fp32 MFMA, 6 / 3 / 1 = split-bf16 products (sbl_set_matmul_precision)
 
 #define ST_TH 8
 #define ST_TW 16
@@ -120,6 +122,190 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     __syncthreads();
     if (tid < 128) atomicAdd(stats + tid, (double)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
     sbl_stamp_end(stamp);
+}
+
+// ------------------------------------------------------------------ pass 1 on the bf16 MFMA pipe (split-bf16 modes)
+// Same tile, patch and epilogue; the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split exactly into bf16
+// planes (bf16_split.h): 6 / 3 / 1 plane products per 32x32x16 block instead of 8 fp32 MFMAs of twice the cycles.
+//   K order: k-step j = the tap rows r = 2j and 2j+1 (r = kt*7 + kh, 35 rows), 7 kw + one zero column each, so the MFMA A
+//     operand of a lane (pixel l&31, k = 8*(l>>5)..+7) is EIGHT CONSECUTIVE floats of one patch row: four aligned 8-byte LDS
+//     reads, split in registers - the pixel operand never takes a second trip through LDS.  18 k-steps (K = 288, 245 live).
+//   Weights: split once per workgroup into LDS in B-fragment order ([k-step][channel half][plane][lane] x 16 bytes,
+//     108 KB for three planes), resident for the workgroup's lifetime: one ds_read_b128 per fragment, conflict free.
+//   One persistent workgroup per CU (108 KB + two 16.8 KB patch buffers); the next tile's patch is fetched into registers
+//     before the contraction and written to the idle buffer after it, so the global round trip hides under 216 MFMAs.
+#define SB_KS 18
+__host__ __device__ constexpr int sb_rowoff(int r) { return ((r < 35 ? r : 34) / 7) * ST_PFS + ((r < 35 ? r : 34) % 7) * ST_PWS; }
+#define SB_PATCH (ST_PT * ST_PFS)                  // floats
+#define SB_PRE ((SB_PATCH + 255) / 256)            // patch floats per thread
+
+// (measured and not kept: lane = patch column, wave = row phase, which makes the (frame, row) arithmetic scalar - 27 narrower
+// loads per thread instead of 17 cost more than the index arithmetic saves: forward 629 -> 682 us)
+__device__ __forceinline__ void sb_fetch_patch(float (&pre)[SB_PRE], const float* __restrict__ x, int tile, int TX, int TY, int T,
+                                               int H, int W, int tid) {
+    const int tx = tile % TX, ty = (tile / TX) % TY, img = tile / (TX * TY);
+    const int n = img / T, t = img - n * T;
+    const int ih0 = 2 * ty * ST_TH - 3, iw0 = 2 * tx * ST_TW - 3;
+#pragma unroll
+    for (int u = 0; u < SB_PRE; ++u) {
+        const int i = tid + u * 256;
+        const int c = i % ST_PWS, r = (i / ST_PWS) % ST_PH, f = i / ST_PFS;
+        const int tt = t + f - 2, ih = ih0 + r, iw = iw0 + c;
+        float v = 0.f;
+        if (i < SB_PATCH && c < ST_PW && (unsigned)tt < (unsigned)T && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            v = x[(((long)n * T + tt) * H + ih) * W + iw];
+        pre[u] = v;
+    }
+}
+__device__ __forceinline__ void sb_put_patch(float* patch, const float (&pre)[SB_PRE], int tid) {
+#pragma unroll
+    for (int u = 0; u < SB_PRE; ++u)
+        if (tid + u * 256 < SB_PATCH) patch[tid + u * 256] = pre[u];
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void stem_conv_fwd_bf_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ out, double* __restrict__ stats, int N,
+                                                               int T, int H, int W, int Ho, int Wo, int TY, int TX,
+                                                               int ntiles, unsigned long long* stamp) {
+    using Tm = BfTerms<NT>;
+    constexpr int NPL = Tm::NPL;
+    sbl_stamp_begin(stamp);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
+    unsigned char* wsm = sb_smem;                                              // SB_KS * 2 * NPL fragments of 1 KB
+    float* patch0 = reinterpret_cast<float*>(sb_smem + SB_KS * 2 * NPL * 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+
+    // weights -> bf16 planes in fragment order: lane ln of fragment (j, c) holds channel c*32 + (ln&31), taps (row 2j + (ln>>5), kw 0..7)
+    for (int u = tid; u < SB_KS * 2 * 64; u += 256) {
+        const int ln = u & 63, c = (u >> 6) & 1, j = u >> 7;
+        const int co = c * 32 + (ln & 31), r = 2 * j + (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (r < 35 && i < 7) ? w[co * ST_K + r * 7 + i] : 0.f;
+        uint2 lo[NPL], hi[NPL];
+        bf_split4<NPL>(make_float4(v[0], v[1], v[2], v[3]), lo);
+        bf_split4<NPL>(make_float4(v[4], v[5], v[6], v[7]), hi);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            *reinterpret_cast<uint4*>(wsm + (((j * 2 + c) * NPL + pl) * 64 + ln) * 16) = make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y);
+    }
+
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;      // this lane's A-operand pixel inside the tile
+    const int abase = py * 2 * ST_PWS + px * 2;
+    float pre[SB_PRE];
+    int cur = 0;
+    if ((int)blockIdx.x < ntiles) {
+        sb_fetch_patch(pre, x, blockIdx.x, TX, TY, T, H, W, tid);
+        sb_put_patch(patch0, pre, tid);
+    }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % TX;
+        const int ty = (tile / TX) % TY;
+        const int img = tile / (TX * TY);
+        const float* patch = patch0 + cur * SB_PATCH;
+        const int next = tile + (int)gridDim.x;
+        if (next < ntiles) sb_fetch_patch(pre, x, next, TX, TY, T, H, W, tid);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        // software pipeline over the 18 k-steps (one wave per SIMD: nothing else hides an LDS round trip): during the MFMAs of
+        // step j the wave splits the pixel floats of step j+1 (read during step j-1) and reads the weight fragments of step
+        // j+1 and the pixel floats of step j+2; scheduling groups spread that work through the MFMA shadows.
+        float2 raw[2][4];
+        bf16x8 a[2][NPL], b[2][2][NPL];
+        auto read_raw = [&](int j, float2 (&q)[4]) {
+            const float2* ap = reinterpret_cast<const float2*>(patch + abase + (half ? sb_rowoff(2 * j + 1) : sb_rowoff(2 * j)));
+            q[0] = ap[0]; q[1] = ap[1]; q[2] = ap[2]; q[3] = ap[3];
+        };
+        auto split_raw = [&](const float2 (&q)[4], bf16x8 (&f)[NPL]) {
+            uint2 lo[NPL], hi[NPL];
+            bf_split4<NPL>(make_float4(q[0].x, q[0].y, q[1].x, q[1].y), lo);
+            bf_split4<NPL>(make_float4(q[2].x, q[2].y, q[3].x, q[3].y), hi);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) f[pl] = __builtin_bit_cast(bf16x8, make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y));
+        };
+        auto read_b = [&](int j, bf16x8 (&f)[2][NPL]) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) f[c][pl] = *reinterpret_cast<const bf16x8*>(wsm + (((j * 2 + c) * NPL + pl) * 64 + lane) * 16);
+        };
+        read_raw(0, raw[0]);
+        read_b(0, b[0]);
+        read_raw(1, raw[1]);
+        split_raw(raw[0], a[0]);
+#pragma unroll
+        for (int j = 0; j < SB_KS; ++j) {
+            const int cur = j & 1, nxt = cur ^ 1;
+            if (j + 1 < SB_KS) {
+                read_b(j + 1, b[nxt]);
+                split_raw(raw[nxt], a[nxt]);
+            }
+            if (j + 2 < SB_KS) read_raw(j + 2, raw[cur]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < Tm::N; ++t) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][Tm::pa(t)], b[cur][c][Tm::pb(t)], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2 * Tm::N; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (12 * NPL + 6 + 2 * Tm::N - 1) / (2 * Tm::N), 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        // D: col (lane&31) = channel, row = pixel (r&3) + 8*(r>>2) + 4*half of this wave's 32 pixels
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oh = ty * ST_TH + 2 * wave + (m >> 4), ow = tx * ST_TW + (m & 15);
+            if (oh < Ho && ow < Wo) {
+                float* o = out + (((long)img * Ho + oh) * Wo + ow) * 64 + l31;
+                o[0] = acc[0][r];
+                o[32] = acc[1][r];
+                s1[0] += acc[0][r];
+                s2[0] += acc[0][r] * acc[0][r];
+                s1[1] += acc[1][r];
+                s2[1] += acc[1][r] * acc[1][r];
+            }
+        }
+        if (next < ntiles) sb_put_patch(patch0 + (cur ^ 1) * SB_PATCH, pre, tid);
+        __syncthreads();       // next patch complete; every wave is done reading this one
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32, 64);
+        s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    float (*red)[128] = reinterpret_cast<float (*)[128]>(patch0);      // the loop's last barrier retired every patch read
+    if (half == 0) {
+        red[wave][l31] = s1[0];
+        red[wave][32 + l31] = s1[1];
+        red[wave][64 + l31] = s2[0];
+        red[wave][96 + l31] = s2[1];
+    }
+    __syncthreads();
+    if (tid < 128) atomicAdd(stats + tid, (double)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+    sbl_stamp_end(stamp);
+}
+template <int NT>
+static int stem_launch_fwd_bf(const float* x, const float* w, float* conv_out, double* stats, int N, int T, int H, int W, int Ho,
+                              int Wo, int TY, int TX, int ntiles, hipStream_t s) {
+    constexpr int lds = SB_KS * 2 * BfTerms<NT>::NPL * 1024 + 2 * SB_PATCH * 4;
+    static bool set = false;
+    if (!set) {
+        SBL_HIP(hipFuncSetAttribute((const void*)stem_conv_fwd_bf_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        set = true;
+    }
+    const int grid = ntiles < 256 ? ntiles : 256;          // persistent: one workgroup per CU
+    hipLaunchKernelGGL(stem_conv_fwd_bf_kernel<NT>, dim3(grid), dim3(256), lds, s, x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX,
+                       ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
+    return 0;
 }
 
 // ------------------------------------------------------------------ BN finalize (shared with the trunk)
@@ -372,6 +558,132 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     sbl_stamp_end(stamp);
 }
 
+// ------------------------------------------------------------------ backward pass 2 on the bf16 MFMA pipe (split-bf16 modes)
+// Same tiles, dconv recomputation and atomics; the contraction over the tile's 128 pixels runs as 8 k-steps (one 16-pixel row
+// each) of v_mfma_f32_32x32x16_bf16.  dconv sits TRANSPOSED in LDS ([co][pixel], rows of 132 floats) so a lane's A operand
+// (channel l&31, pixels 8*(l>>5)..+7 of the row) is two aligned 16-byte reads; the B operand (tap l&31 of the wave's two
+// 32-tap tiles, the same 8 pixels) is eight stride-2 floats of the patch.  Both are split into bf16 planes in registers.
+#define SB_DT 132
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void stem_wgrad_bf_kernel(const float* __restrict__ x, const float* __restrict__ conv,
+                                                            const float* __restrict__ dpool, const uint8_t* __restrict__ argmax,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const double* __restrict__ sums, float* __restrict__ dw,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int T,
+                                                            int H, int W, int Ho, int Wo, int Hp, int Wp, int TY, int TX,
+                                                            int ntiles, unsigned long long* stamp) {
+    using Tm = BfTerms<NT>;
+    constexpr int NPL = Tm::NPL;
+    sbl_stamp_begin(stamp);
+    __shared__ __attribute__((aligned(16))) float Dt[64 * SB_DT];
+    __shared__ float patch[ST_PT * ST_PFS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const double cnt = (double)N * T * Ho * Wo;
+    if (blockIdx.x == 0 && tid < 64) {
+        dbeta[tid] = (float)sums[tid];
+        dgamma[tid] = (float)sums[64 + tid];
+    }
+    const int c4 = (tid & 15) * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c4);
+    float mg[4], mgx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mg[k] = (float)(sums[c4 + k] / cnt);
+        mgx[k] = (float)(sums[64 + c4 + k] / cnt);
+    }
+    const int k0 = (2 * wave) * 32 + l31, k1 = k0 + 32;   // this lane's two B-operand taps
+    const int boff0 = st_koff(k0) + 16 * half, boff1 = st_koff(k1) + 16 * half;      // + its 8 pixels' first column
+    const int aoff = l31 * SB_DT + 8 * half;
+
+    f32x16 acc[2][2];   // [co tile][k tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % TX;
+        const int ty = (tile / TX) % TY;
+        const int img = tile / (TX * TY);
+        const int n = img / T, t = img - n * T;
+        __syncthreads();
+        st_load_patch(patch, x, n, t, ty, tx, T, H, W, tid);
+        // dconv tile -> Dt[co][pixel]; thread = (pixel group, channel quad), 8 passes of 16 pixels
+#pragma unroll 2
+        for (int ps = 0; ps < 8; ++ps) {
+            const int pix = ps * 16 + (tid >> 4);
+            const int oh = ty * ST_TH + (pix >> 4), ow = tx * ST_TW + (pix & 15);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oh < Ho && ow < Wo) {
+                const float4 v = *reinterpret_cast<const float4*>(conv + (((long)img * Ho + oh) * Wo + ow) * 64 + c4);
+                float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
+                float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+                float g[4];
+                stem_gather_g(dpool, argmax, img, oh, ow, Hp, Wp, c4, y, g);
+                d.x = ga.x * is.x * (g[0] - mg[0] - xh[0] * mgx[0]);
+                d.y = ga.y * is.y * (g[1] - mg[1] - xh[1] * mgx[1]);
+                d.z = ga.z * is.z * (g[2] - mg[2] - xh[2] * mgx[2]);
+                d.w = ga.w * is.w * (g[3] - mg[3] - xh[3] * mgx[3]);
+            }
+            Dt[(c4 + 0) * SB_DT + pix] = d.x;
+            Dt[(c4 + 1) * SB_DT + pix] = d.y;
+            Dt[(c4 + 2) * SB_DT + pix] = d.z;
+            Dt[(c4 + 3) * SB_DT + pix] = d.w;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int sr = 0; sr < 8; ++sr) {          // k-step = pixel row sr of the tile
+            bf16x8 a[2][NPL], b[2][NPL];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4* ap = reinterpret_cast<const float4*>(Dt + i * 32 * SB_DT + aoff + sr * 16);
+                uint2 lo[NPL], hi[NPL];
+                bf_split4<NPL>(ap[0], lo);
+                bf_split4<NPL>(ap[1], hi);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) a[i][pl] = __builtin_bit_cast(bf16x8, make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* bp = patch + sr * 2 * ST_PWS + (j ? boff1 : boff0);
+                uint2 lo[NPL], hi[NPL];
+                bf_split4<NPL>(make_float4(bp[0], bp[2], bp[4], bp[6]), lo);
+                bf_split4<NPL>(make_float4(bp[8], bp[10], bp[12], bp[14]), hi);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) b[j][pl] = __builtin_bit_cast(bf16x8, make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < Tm::N; ++tt)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][Tm::pa(tt)], b[j][Tm::pb(tt)], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D: col (lane&31) = tap within the k tile, row = co within the co tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = (2 * wave + j) * 32 + l31;
+            if (k < ST_K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    atomicAdd(dw + co * ST_K + k, acc[i][j][r]);
+                }
+            }
+        }
+    sbl_stamp_end(stamp);
+}
+
 // ------------------------------------------------------------------ host entry points
 static int stem_dims(const char* who, int N, int T, int H, int W) {
     SBL_REQUIRE(N > 0 && T > 0 && H >= 8 && W >= 8 && H % 4 == 0 && W % 4 == 0, "%s: bad clip dims N=%d T=%d H=%d W=%d (H,W multiples of 4)", who, N, T, H, W);
@@ -388,6 +700,14 @@ extern "C" int sbl_stem_conv_fwd(const float* x, const float* w, float* conv_out
     const long ntiles = (long)N * T * TY * TX;
     SBL_REQUIRE(ntiles < (1L << 31), "sbl_stem_conv_fwd: too many tiles");
     SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 128, s));
+    if (g_sbl_prec) {
+        int e = g_sbl_prec == 6 ? stem_launch_fwd_bf<6>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
+              : g_sbl_prec == 3 ? stem_launch_fwd_bf<3>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
+                                : stem_launch_fwd_bf<1>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s);
+        if (e) return e;
+        SBL_LAUNCH_CHECK("sbl_stem_conv_fwd(bf16)");
+        return 0;
+    }
     const int grid = (int)(ntiles < 512 ? ntiles : 512);   // persistent: 2 workgroups per CU (LDS-bound)
     hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(grid), dim3(256), 0, s, x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY,
                        TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
@@ -456,6 +776,16 @@ extern "C" int sbl_stem_wgrad(const float* x, const float* conv_out, const float
     SBL_REQUIRE(ntiles < (1L << 31), "sbl_stem_wgrad: too many tiles");
     SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 64 * ST_K, s));
     const int grid = (int)(ntiles < 768 ? ntiles : 768);   // 3 workgroups per CU (52 KB LDS each)
+    if (g_sbl_prec) {
+#define SBL_SWG_(NT) hipLaunchKernelGGL(stem_wgrad_bf_kernel<NT>, dim3(grid), dim3(256), 0, s, x, conv_out, dpooled, argmax, mean, invstd, gamma, \
+                       beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM))
+        if (g_sbl_prec == 6) SBL_SWG_(6);
+        else if (g_sbl_prec == 3) SBL_SWG_(3);
+        else SBL_SWG_(1);
+#undef SBL_SWG_
+        SBL_LAUNCH_CHECK("sbl_stem_wgrad(bf16)");
+        return 0;
+    }
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, conv_out, dpooled, argmax, mean, invstd, gamma,
                        beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
     SBL_LAUNCH_CHECK("sbl_stem_wgrad");

@@ -2,7 +2,7 @@
 import csv, collections, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('stem_conv_fwd')]
+idx = [i for i, r in enumerate(rows) if 'stem_conv_fwd' in r['Kernel_Name']]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
 a, b = idx[which], idx[which + 1]
 step = rows[a:b]
