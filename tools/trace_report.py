@@ -13,6 +13,9 @@ for s, e in ev[1:]:
     if s > ce: cov += ce - cs; cs, ce = s, e
     else: ce = max(ce, e)
 cov += ce - cs
+starts = [int(rows[i]['Start_Timestamp']) for i in idx]
+per = [(b_ - a_) / 1e6 for a_, b_ in zip(starts[:-1], starts[1:])][-4:]
+print("step-to-step period over the last %d steps: mean %.2f ms (%s) - the teacher-forcing coin patterns differ in decoder work; the step below is one of them" % (len(per), sum(per) / len(per), " ".join("%.1f" % p for p in per)))
 print("step wall %.2f ms, %d kernels, union busy %.2f ms, sum %.2f ms" % ((t1 - t0) / 1e6, len(step), cov / 1e6, sum(e - s for s, e in ev) / 1e6))
 def short(n):
     n = re.sub(r'\(.*', '', n)
