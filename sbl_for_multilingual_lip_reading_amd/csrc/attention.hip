@@ -48,10 +48,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
                                                             int mask_kind, const uint8_t* __restrict__ mask, int B, int H,
                                                             SegDesc segs, int Lk_fixed, float scale, uint32_t thresh,
                                                             float keep_scale, const uint64_t* __restrict__ seed,
-                                                            uint64_t offset, unsigned long long* stamp) {
+                                                            uint64_t offset, int sz, unsigned long long* stamp) {
     sbl_stamp_begin(stamp);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Qs = smem, *Ks = smem + AT_SZ, *Vs = smem + 2 * AT_SZ, *Ss = smem + 3 * AT_SZ;
+    float *Qs = smem, *Ks = smem + sz, *Vs = smem + 2 * sz, *Ss = smem + 3 * sz;      // sz = rows actually needed x AT_LD
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // block -> (segment, batch row, head).  Self-attention (Lk_fixed == 0): keys are the segment's own rows;
     // cross-attention: every segment attends to the same (B, Lk_fixed) key/value rows.
@@ -116,11 +116,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                                                             float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
                                                             float* __restrict__ dv, long lddv, int B, int H, SegDesc segs,
                                                             int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
-                                                            const uint64_t* __restrict__ seed, uint64_t offset, unsigned long long* stamp) {
+                                                            const uint64_t* __restrict__ seed, uint64_t offset, int sz, unsigned long long* stamp) {
     sbl_stamp_begin(stamp);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Qs = smem, *Ks = smem + AT_SZ, *Vs = smem + 2 * AT_SZ, *Gs = smem + 3 * AT_SZ, *Ps = smem + 4 * AT_SZ,
-          *Ds = smem + 5 * AT_SZ;   // Gs = dO, Ps = (dropped) P then dS, Ds = dP
+    float *Qs = smem, *Ks = smem + sz, *Vs = smem + 2 * sz, *Gs = smem + 3 * sz, *Ps = smem + 4 * sz,
+          *Ds = smem + 5 * sz;   // Gs = dO, Ps = (dropped) P then dS, Ds = dP; sz = rows actually needed x AT_LD
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sidx = blockIdx.x / (B * H);
     const int b = (blockIdx.x / H) % B, h = blockIdx.x % H;
@@ -622,6 +622,14 @@ static int at_check(const char* who, int B, int H, const SegDesc& d, int Lk_fixe
     return 0;
 }
 
+// LDS floats per staged matrix of the workgroup kernels: the longest padded side of any segment x the row stride.  (Sized by
+// the problem, not by the 64-row maximum: at the encoder's 29 frames the backward kernel takes 50 KB instead of 100 KB and
+// fits beside the other stream's GEMM workgroups - in the step its launches waited for a whole CU's LDS before.)
+static int at_rows_sz(const SegDesc& d, int nseg, int Lk_fixed) {
+    int m = Lk_fixed;
+    for (int i = 0; i < nseg; ++i) m = d.L[i] > m ? d.L[i] : m;
+    return ((m + 31) & ~31) * AT_LD;
+}
 static int at_attr(const void* fn, size_t lds, bool* flags) {
     int dev = 0;
     SBL_HIP(hipGetDevice(&dev));
@@ -657,12 +665,13 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
         SBL_LAUNCH_CHECK("sbl_attention_fwd(small)");
         return 0;
     }
-    const size_t lds = sizeof(float) * 4 * AT_SZ;
+    const int sz = at_rows_sz(d, nseg, Lk_fixed);
+    const size_t lds = sizeof(float) * 4 * sz;
     static bool attr_set[64] = {false};
-    if (int e = at_attr((const void*)attention_fwd_kernel, lds, attr_set)) return e;
+    if (int e = at_attr((const void*)attention_fwd_kernel, sizeof(float) * 4 * AT_SZ, attr_set)) return e;
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(nseg * B * H), dim3(256), lds, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, o,
                        ldo, p_out, mask_kind, mask, B, H, d, Lk_fixed, scale, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u,
-                       1.f / (1.f - drop_p), seed, offset, sbl_next_stamp_slot(SBL_KID_ATTENTION));
+                       1.f / (1.f - drop_p), seed, offset, sz, sbl_next_stamp_slot(SBL_KID_ATTENTION));
     SBL_LAUNCH_CHECK("sbl_attention_fwd");
     return 0;
 }
@@ -732,12 +741,13 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
         SBL_HIP(hipMemset2DAsync(dk, lddk * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
         SBL_HIP(hipMemset2DAsync(dv, lddv * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
     }
-    const size_t lds = sizeof(float) * 6 * AT_SZ;
+    const int sz = at_rows_sz(d, nseg, Lk_fixed);
+    const size_t lds = sizeof(float) * 6 * sz;
     static bool attr_set[64] = {false};
-    if (int e = at_attr((const void*)attention_bwd_kernel, lds, attr_set)) return e;
+    if (int e = at_attr((const void*)attention_bwd_kernel, sizeof(float) * 6 * AT_SZ, attr_set)) return e;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(nseg * B * H), dim3(256), lds, (hipStream_t)stream, dout, lddo, q, ldq, k, ldk,
                        v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
-                       drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, sbl_next_stamp_slot(SBL_KID_ATTENTION));
+                       drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, sz, sbl_next_stamp_slot(SBL_KID_ATTENTION));
     SBL_LAUNCH_CHECK("sbl_attention_bwd");
     return 0;
 }

@@ -56,6 +56,22 @@ def test_gemm(ops, ta, tb, M, N, K):
     assert maxdiff(C, ref) < 2e-6 * max(K, 16) ** 0.5 * 4
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (1, 0)])
+def test_gemm_big_tiles_odd_slab_count(ops, ta, tb):
+    """128x128 tiles (>= 4096 64x64 tiles) with K = 63 slabs of 16 + a ragged tail: the split-bf16 body of the larger tiles
+    unrolls its K loop by two and runs the missing slab on zeros (out-of-range loads), the 64x64 ring issues loads up to five
+    slabs past the end of K - both must leave the product untouched."""
+    M, N, K = 4160, 4096, 16 * 63 + 4
+    g = torch.Generator().manual_seed(5)
+    A = torch.rand((K, M) if ta else (M, K), generator=g) * 2 - 1
+    B = torch.rand((N, K) if tb else (K, N), generator=g) * 2 - 1
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(ta, tb, M, N, K, Ad, A.size(1), Bd, B.size(1), C, N)
+    ref = (Ad.t() if ta else Ad).double() @ (Bd.t() if tb else Bd).double()
+    assert maxdiff(C, ref) < 2e-6 * K ** 0.5 * 4
+
+
 def test_gemm_epilogues_and_strides(ops):
     M, N, K = 70, 130, 96
     A, W, b = U("eA", (M, K + 8)), U("eW", (N, K)), U("eb", (N,))
@@ -266,6 +282,36 @@ def test_stem_fwd_bwd(ops, N, T, H, W):
     ref_e = O.stem(sd_e, x.unsqueeze(1), False, prefix="s")
     out_e = ops.StemFn.apply(x.to(DEV), w.detach(), g.detach(), b.detach(), rm, rv, False, 0.1, 1e-5)
     assert maxdiff(out_e, ref_e.permute(0, 2, 3, 4, 1).reshape(out_e.shape)) < 2e-5
+
+
+@pytest.mark.parametrize("mode,tol_out,tol_grad", [("bf16x3", 2e-4, 2e-3), ("bf16", 4e-2, 0.15)])
+def test_stem_reduced_precision_modes(mode, tol_out, tol_grad):
+    """The stem's two contractions follow sbl_set_matmul_precision: the 3-product and plain-bf16 instantiations of the bf16
+    kernels against the fp32-MFMA kernels on the same input (the 6-product mode is held to the oracle's tolerances by
+    test_stem_fwd_bwd through the `ops` fixture)."""
+    from sbl_for_multilingual_lip_reading_amd import ops
+    N, T, H, W = 2, 3, 40, 56
+    x = torch.from_numpy(detfill.normal("stemr.x", (N, T, H, W))).to(DEV)
+    w0 = U("stemr.w", (64, 1, 5, 7, 7), 0.08).to(DEV)
+    g0, b0 = (1 + 0.3 * U("stemr.g", (64,))).to(DEV), U("stemr.b", (64,), 0.2).to(DEV)
+    res = {}
+    try:
+        for m in ("f32", mode):
+            ops.set_matmul_precision(m)
+            w, g, b = (t.clone().requires_grad_(True) for t in (w0, g0, b0))
+            rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+            out = ops.StemFn.apply(x, w, g, b, rm, rv, True, 0.1, 1e-5)
+            dy = U("stemr.dy", tuple(out.shape)).to(DEV)
+            out.backward(dy)
+            res[m] = (out.detach(), w.grad.clone(), g.grad.clone(), b.grad.clone())
+    finally:
+        ops.set_matmul_precision("f32")
+    ref, got = res["f32"], res[mode]
+    # pool-argmax and ReLU decisions within the mode's error flip (plain bf16: 7 % of the weight gradient in L2); an indexing
+    # mistake in a kernel would be O(1)
+    assert float((got[0] - ref[0]).norm() / ref[0].norm()) < tol_out
+    for a, r in zip(got[1:], ref[1:]):
+        assert float((a - r).norm() / r.norm()) < tol_grad
 
 
 def test_stem_pool_tie_break_on_constant_frames(ops):
