@@ -181,13 +181,18 @@ class LaunchRecorder:
                 rows = sum(a[2][i] for i in range(a[1]))
                 fl = sum(2.0 * a[7][p] * a[8][p] * rows for p in range(a[0]))
                 by = sum(4.0 * ((a[7][p] + a[8][p]) * rows + 2 * a[7][p] * a[8][p]) for p in range(a[0]))
-            elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_dgrad_bnstats", "sbl_conv2d_wgrad"):
+            elif name == "sbl_conv1x1s2_dgrad_compact":      # the downsample branch's input gradient on its even/even support
+                nimg, h, w, cin, cout = a[3:8]
+                fl = 2.0 * nimg * ((h + 1) // 2) * ((w + 1) // 2) * cout * cin
+                by = 4.0 * (nimg * ((h + 1) // 2) * ((w + 1) // 2) * (cin + cout) + cout * cin)
+                desc = "conv2d_dgrad(1x1/s2 compact) n%d %dx%d c%d->%d" % (nimg, h, w, cin, cout)
+            elif name in ("sbl_conv2d_fwd", "sbl_conv2d_dgrad", "sbl_conv2d_dgrad_bnstats", "sbl_conv2d_dgrad_fused", "sbl_conv2d_wgrad"):
                 off = 2 if name == "sbl_conv2d_fwd" else 0
                 nimg, h, w, cin, cout, kh, kw, stride, pad = a[3 + off:12 + off]
                 ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
                 fl = 2.0 * nimg * ho * wo * cout * kh * kw * cin
                 by = 4.0 * (nimg * h * w * cin + nimg * ho * wo * cout + cout * kh * kw * cin)
-                desc = "%s n%d %dx%d c%d->%d k%d s%d" % (name[4:].replace("_bnstats", ""), nimg, h, w, cin, cout, kh, stride)
+                desc = "%s n%d %dx%d c%d->%d k%d s%d" % (name[4:].replace("_bnstats", "").replace("_fused", ""), nimg, h, w, cin, cout, kh, stride)
             elif name == "sbl_stem_conv_fwd" or name == "sbl_stem_wgrad":
                 n, t, h, w = a[4:8] if name == "sbl_stem_conv_fwd" else a[12:16]
                 pix = n * t * (h // 2) * (w // 2)

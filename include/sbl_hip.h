@@ -167,6 +167,7 @@ int sbl_conv2d_dgrad(const float* dy, const float* w_dgrad, float* dx, int NIMG,
 int sbl_conv2d_dgrad_bnstats(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* act,
                              const float* pre, const float* mean, const float* invstd, double* sums,
+                             int sums_zeroed /* sums already hold zeros (a pooled memset): skip the call's own */,
                              sbl_stream_t stream);
 /* The general form (any stride; every fused operand may be NULL) - what BasicBlock's backward needs so that no separate
  * pass touches dx (video_frontend.py:28-41):
@@ -180,15 +181,15 @@ int sbl_conv2d_dgrad_bnstats(const float* dy, const float* w_dgrad, float* dx, i
 int sbl_conv2d_dgrad_fused(const float* dy, const float* w_dgrad, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                            int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* addend,
                            const float* act, const float* pre, const float* mean, const float* invstd, const float* pre2,
-                           const float* mean2, const float* invstd2, double* sums, sbl_stream_t stream);
+                           const float* mean2, const float* invstd2, double* sums, int sums_zeroed, sbl_stream_t stream);
 /* Input gradient of the 1x1 / stride-2 downsample convolution on its own support: dx_compact (NIMG, ceil(H/2), ceil(W/2),
  * Cin) = dy (NIMG, ceil(H/2), ceil(W/2), Cout) * w; the other three quarters of the full-size gradient are zeros that
  * nobody needs to write (sbl_conv2d_dgrad_fused adds the compact form to conv1's gradient). */
 int sbl_conv1x1s2_dgrad_compact(const float* dy, const float* w_dgrad, float* dx_compact, int NIMG, int H, int W, int Cin,
                                 int Cout, void* ws, long ws_bytes, sbl_stream_t stream);
-/* dw_ohwi zeroed by the call, then split-K float atomics */
+/* dw_ohwi zeroed by the call (unless dw_zeroed: the caller hands over zeros), then split-K float atomics */
 int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, int NIMG, int H, int W, int Cin, int Cout,
-                     int KH, int KW, int stride, int pad, sbl_stream_t stream);
+                     int KH, int KW, int stride, int pad, int dw_zeroed, sbl_stream_t stream);
 /* AdaptiveAvgPool2d(1): (NIMG,HW,C) -> (NIMG,C): video_frontend.py:53,87-88 */
 int sbl_avgpool_fwd(const float* x, float* y, int NIMG, int HW, int C, sbl_stream_t stream);
 int sbl_avgpool_bwd(const float* dy, float* dx, int NIMG, int HW, int C, sbl_stream_t stream);
@@ -282,6 +283,11 @@ int sbl_embed_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, in
 int sbl_fusion_fwd(const float* a, const float* b, float* a2, float* b2, int B, int L, int D, sbl_stream_t stream);
 int sbl_fusion_bwd(const float* da2, const float* db2, float* da, float* db, int B, int L, int D,
                    sbl_stream_t stream);
+/* Decoder.preprocess (decoder.py:62-77): strip IGNORE_ID, <sos> + ids (input form) / ids (label form), both padded with <eos>
+   to maxlen; int64 (N,To) -> two int64 (N,maxlen).  padded1 != NULL: a second target set (the r2l direction) in the same launch. */
+int sbl_decoder_preprocess(const int64_t* padded0, const int64_t* padded1, int64_t* ys_in0, int64_t* ys_out0, int64_t* ys_in1,
+                           int64_t* ys_out1, int N, int To, int maxlen, int64_t sos, int64_t eos, int64_t ignore,
+                           sbl_stream_t stream);
 /* ys[b, step+1] = use_argmax ? argmax_c pred[b,c] : gold[b, step]: decoder.py:173-186.
  * use_argmax: host int, or if coins_dev != NULL coins_dev[step] (device int32, for graph replay). */
 int sbl_argmax_select(const float* pred, long ldp, const int64_t* gold, long ldg, int64_t* ys, long ldy, int step,

@@ -28,10 +28,10 @@ SIGNATURES = {
     "sbl_conv_wgrad_unpack": [P, P, I, I, I, I, I, P],
     "sbl_conv2d_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "sbl_conv2d_dgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P],
-    "sbl_conv2d_dgrad_bnstats": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P],
-    "sbl_conv2d_dgrad_fused": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P, P, P, P, P],
+    "sbl_conv2d_dgrad_bnstats": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, I, P],
+    "sbl_conv2d_dgrad_fused": [P, P, P, I, I, I, I, I, I, I, I, I, P, L, P, P, P, P, P, P, P, P, P, I, P],
     "sbl_conv1x1s2_dgrad_compact": [P, P, P, I, I, I, I, I, P, L, P],
-    "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "sbl_conv2d_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "sbl_avgpool_fwd": [P, P, I, I, I, P],
     "sbl_avgpool_bwd": [P, P, I, I, I, P],
     "sbl_dropout": [P, P, L, F, P, U64, P],
@@ -58,6 +58,7 @@ SIGNATURES = {
     "sbl_fusion_fwd": [P, P, P, P, I, I, I, P],
     "sbl_fusion_bwd": [P, P, P, P, I, I, I, P],
     "sbl_argmax_select": [P, L, P, L, P, L, I, I, P, I, I, P],
+    "sbl_decoder_preprocess": [P, P, P, P, P, P, I, I, I, L, L, L, P],
     "sbl_smoothed_ce_fwd": [P, P, P, I, I, F, I, P],
     "sbl_smoothed_ce_bwd": [P, P, P, P, P, I, I, F, I, P],
     "sbl_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],

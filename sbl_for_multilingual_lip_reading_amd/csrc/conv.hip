@@ -117,6 +117,7 @@ struct DgradFuse {
     const float* mean2;
     const float* inv2;
     double* sums;
+    int sums_zeroed;       // the caller hands over zeros (one pooled memset per step instead of one per convolution)
 };
 static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, void* ws, long ws_bytes, sbl_stream_t stream,
@@ -128,7 +129,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     const bool fused = f.addend || f.sums;
     if (f.sums) {
         SBL_REQUIRE(f.y && f.x && f.mean && f.inv && (!f.x2 || (f.mean2 && f.inv2)), "sbl_conv2d_dgrad_fused: incomplete BatchNorm operands");
-        SBL_HIP(hipMemsetAsync(f.sums, 0, sizeof(double) * (f.x2 ? 4 : 2) * Cin, s));
+        if (!f.sums_zeroed) SBL_HIP(hipMemsetAsync(f.sums, 0, sizeof(double) * (f.x2 ? 4 : 2) * Cin, s));
     }
     SBL_REQUIRE(!f.addend || f.add_class00 == (stride == 2), "sbl_conv2d_dgrad_fused: the compact addend belongs to stride-2 convolutions (and only to them)");
     SBL_REQUIRE(!compact_out || (KH == 1 && stride == 2 && !fused), "sbl_conv2d_dgrad: compact output is the 1x1 / stride-2 case");
@@ -263,18 +264,18 @@ extern "C" int sbl_conv2d_dgrad(const float* dy, const float* wt, float* dx, int
 extern "C" int sbl_conv2d_dgrad_bnstats(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                                         int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* act,
                                         const float* pre, const float* mean, const float* invstd, double* sums,
-                                        sbl_stream_t stream) {
+                                        int sums_zeroed, sbl_stream_t stream) {
     SBL_REQUIRE(act && pre && mean && invstd && sums, "sbl_conv2d_dgrad_bnstats: null statistics operand");
     return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
-                             DgradFuse{nullptr, 0, act, pre, mean, invstd, nullptr, nullptr, nullptr, sums}, 0);
+                             DgradFuse{nullptr, 0, act, pre, mean, invstd, nullptr, nullptr, nullptr, sums, sums_zeroed}, 0);
 }
 extern "C" int sbl_conv2d_dgrad_fused(const float* dy, const float* wt, float* dx, int NIMG, int H, int W, int Cin, int Cout,
                                       int KH, int KW, int stride, int pad, void* ws, long ws_bytes, const float* addend,
                                       const float* act, const float* pre, const float* mean, const float* invstd,
                                       const float* pre2, const float* mean2, const float* invstd2, double* sums,
-                                      sbl_stream_t stream) {
+                                      int sums_zeroed, sbl_stream_t stream) {
     return conv2d_dgrad_impl(dy, wt, dx, NIMG, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes, stream,
-                             DgradFuse{addend, addend && stride == 2, act, pre, mean, invstd, pre2, mean2, invstd2, sums}, 0);
+                             DgradFuse{addend, addend && stride == 2, act, pre, mean, invstd, pre2, mean2, invstd2, sums, sums_zeroed}, 0);
 }
 extern "C" int sbl_conv1x1s2_dgrad_compact(const float* dy, const float* wt, float* dx_compact, int NIMG, int H, int W, int Cin,
                                            int Cout, void* ws, long ws_bytes, sbl_stream_t stream) {
@@ -282,7 +283,7 @@ extern "C" int sbl_conv1x1s2_dgrad_compact(const float* dy, const float* wt, flo
 }
 
 extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int NIMG, int H, int W, int Cin, int Cout,
-                                int KH, int KW, int stride, int pad, sbl_stream_t stream) {
+                                int KH, int KW, int stride, int pad, int dw_zeroed, sbl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_conv("sbl_conv2d_wgrad", NIMG, H, W, Cin, Cout, KH, KW, stride, pad)) return e;
     SBL_REQUIRE(x && dy && dw && sbl_aligned16(x) && sbl_aligned16(dy), "sbl_conv2d_wgrad: null/unaligned pointer");
@@ -290,7 +291,7 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     const int M = Cout, N = KH * KW * Cin, K = NIMG * Ho * Wo;   // reduce over output pixels
     ConvGeom g{NIMG, Ho, Wo, H, W, Cin, KH, KW, stride, pad, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     sbl_geom_finish(g);
-    SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * N, s));
+    if (!dw_zeroed) SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * N, s));
     // split the pixel reduction: 128x128 tiles for the 128+-channel layers (twice the flops per staged byte), 64x64
     // otherwise, and 6 / 12 workgroups per CU so that the uneven last chunks and the atomic epilogues of one
     // workgroup hide behind the others (measured, tools/bench_conv.py: 465/477/511/515 us -> 411/355/437/453 us for

@@ -216,6 +216,44 @@ extern "C" int sbl_argmax_select(const float* pred, long ldp, const int64_t* gol
     return 0;
 }
 
+// ------------------------------------------------------------------ Decoder.preprocess, decoder.py:62-77
+// One thread per target row: strip IGNORE_ID keeping the order, <sos> in front of the input form, <eos> padding to maxlen in
+// both forms.  set = 0 / 1: the l2r / r2l targets of one step in one launch (torch's argsort + gather + where + fills were
+// ~20 launches per direction).
+__global__ void decoder_preprocess_kernel(const int64_t* __restrict__ p0, const int64_t* __restrict__ p1, int64_t* __restrict__ in0,
+                                          int64_t* __restrict__ out0, int64_t* __restrict__ in1, int64_t* __restrict__ out1, int N,
+                                          int To, int maxlen, int64_t sos, int64_t eos, int64_t ignore) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int64_t* p = (blockIdx.y ? p1 : p0) + (long)i * To;
+    int64_t* yi = (blockIdx.y ? in1 : in0) + (long)i * maxlen;
+    int64_t* yo = (blockIdx.y ? out1 : out0) + (long)i * maxlen;
+    for (int t = 0; t < maxlen; ++t) {
+        yi[t] = eos;
+        yo[t] = eos;
+    }
+    yi[0] = sos;
+    int c = 0;
+    for (int t = 0; t < To; ++t) {
+        const int64_t v = p[t];
+        if (v != ignore) {
+            if (c + 1 < maxlen) yi[1 + c] = v;
+            if (c < maxlen) yo[c] = v;
+            ++c;
+        }
+    }
+}
+extern "C" int sbl_decoder_preprocess(const int64_t* padded0, const int64_t* padded1, int64_t* ys_in0, int64_t* ys_out0,
+                                      int64_t* ys_in1, int64_t* ys_out1, int N, int To, int maxlen, int64_t sos, int64_t eos,
+                                      int64_t ignore, sbl_stream_t stream) {
+    SBL_REQUIRE(padded0 && ys_in0 && ys_out0 && N > 0 && To > 0 && maxlen > 1, "sbl_decoder_preprocess: bad args N=%d To=%d maxlen=%d", N, To, maxlen);
+    SBL_REQUIRE(!padded1 || (ys_in1 && ys_out1), "sbl_decoder_preprocess: second target set without outputs");
+    hipLaunchKernelGGL(decoder_preprocess_kernel, dim3(sbl_cdiv(N, 64), padded1 ? 2 : 1), dim3(64), 0, (hipStream_t)stream, padded0,
+                       padded1, ys_in0, ys_out0, ys_in1, ys_out1, N, To, maxlen, sos, eos, ignore);
+    SBL_LAUNCH_CHECK("sbl_decoder_preprocess");
+    return 0;
+}
+
 // ------------------------------------------------------------------ label-smoothed CE: loss.py:27-52
 // one wavefront per row (C <= 64*4).  q = onehot*(1-eps) + (1-onehot)*eps/C (rows do not sum to 1: kept).
 // eps == 0 reduces to plain cross entropy with ignore_index (loss.py:48-50).

@@ -43,6 +43,37 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# One pooled memset per training step instead of one per convolution: the packed weight-gradient buffers (split-K float atomics
+# start from zero) and the BatchNorm-backward sums that ride on input-gradient epilogues are carved from a per-device pool
+# that StemFn.forward - the first node of a step - zeroes with a single launch.  A region is handed out at most once per
+# reset, so it still holds zeros when its kernel runs; without a reset in this process, or when the pool is used up, the
+# takers fall back to a buffer the C call zeroes itself.
+ZERO_POOL_BYTES = 64 << 20        # ResNet-18 trunk weights: 44.7 MB of fp32, + 0.2 MB of fp64 sums
+_ZERO_POOL = {}
+
+
+def zero_pool_reset(dev):
+    st = _ZERO_POOL.get(dev.index)
+    if st is None:
+        st = _ZERO_POOL[dev.index] = {"buf": torch.empty(ZERO_POOL_BYTES, dtype=torch.uint8, device=dev), "off": 0, "armed": False}
+    st["buf"].zero_()
+    st["off"], st["armed"] = 0, True
+
+
+def zero_pool_take(dev, shape, dtype):
+    """A zero-filled tensor from the pool, or None (the caller then allocates and lets the C call zero its buffer)."""
+    st = _ZERO_POOL.get(dev.index)
+    n = 1
+    for d in shape:
+        n *= d
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    if st is None or not st["armed"] or st["off"] + nbytes > ZERO_POOL_BYTES:
+        return None
+    off = st["off"]
+    st["off"] = (off + nbytes + 255) & ~255
+    return st["buf"][off:off + nbytes].view(dtype).view(*shape)
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -964,6 +995,8 @@ class StemFn(torch.autograd.Function):
         x = x.contiguous()
         N, T, H, W = x.shape
         dev = x.device
+        if training and any(ctx.needs_input_grad):
+            zero_pool_reset(dev)          # the step starts here: one memset for every zero-initialised buffer of its backward
         Ho, Wo = H // 2, W // 2
         w2 = w.contiguous().view(64, 245)
         conv = torch.empty(N * T, Ho, Wo, 64, device=dev, dtype=torch.float32)
@@ -1139,18 +1172,24 @@ class ConvBNFn(torch.autograd.Function):
                 nsums = None
                 if fuse:
                     two = prev.get("conv2") is not None
-                    nsums = torch.empty((4 if two else 2) * Cin, device=dev, dtype=torch.float64)
+                    nsums = zero_pool_take(dev, ((4 if two else 2) * Cin,), torch.float64)
+                    pooled = nsums is not None
+                    if not pooled:
+                        nsums = torch.empty((4 if two else 2) * Cin, device=dev, dtype=torch.float64)
                     call("sbl_conv2d_dgrad_fused", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                          _workspace().data_ptr(), WS_BYTES, _p(addend), _p(x), _p(prev["conv"]), _p(prev["mean"]), _p(prev["invstd"]),
-                         _p(prev.get("conv2")), _p(prev.get("mean2")), _p(prev.get("invstd2")), _p(nsums), _s())
+                         _p(prev.get("conv2")), _p(prev.get("mean2")), _p(prev.get("invstd2")), _p(nsums), int(pooled), _s())
                     prev["sums"], prev["dx_ptr"] = nsums, dx.data_ptr()
                 else:
                     call("sbl_conv2d_dgrad_fused", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
-                         _workspace().data_ptr(), WS_BYTES, _p(addend), None, None, None, None, None, None, None, None, _s())
+                         _workspace().data_ptr(), WS_BYTES, _p(addend), None, None, None, None, None, None, None, None, 0, _s())
             elif bi is not None and bi.get("conv") is not None:
-                nsums = torch.empty(2 * Cin, device=dev, dtype=torch.float64)
+                nsums = zero_pool_take(dev, (2 * Cin,), torch.float64)
+                pooled = nsums is not None
+                if not pooled:
+                    nsums = torch.empty(2 * Cin, device=dev, dtype=torch.float64)
                 call("sbl_conv2d_dgrad_bnstats", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
-                     _workspace().data_ptr(), WS_BYTES, _p(x), _p(bi["conv"]), _p(bi["mean"]), _p(bi["invstd"]), _p(nsums), _s())
+                     _workspace().data_ptr(), WS_BYTES, _p(x), _p(bi["conv"]), _p(bi["mean"]), _p(bi["invstd"]), _p(nsums), int(pooled), _s())
                 bi["sums"], bi["dx_ptr"] = nsums, dx.data_ptr()
             else:
                 call("sbl_conv2d_dgrad", _p(dconv), _p(w_dg), _p(dx), NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
@@ -1164,15 +1203,18 @@ class ConvBNFn(torch.autograd.Function):
             side = side_stream(dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
-                call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+                dw_ohwi = zero_pool_take(dev, (Cout, KH, KW, Cin), torch.float32)
+                pooled = dw_ohwi is not None
+                if not pooled:
+                    dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+                call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, int(pooled), _s())
                 call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
             x.record_stream(side)
             dconv.record_stream(side)
             _arm_side_join()
             return dx, None, dgamma, dbeta, None, None, dres_ret, None, None, None, None, None, None, None, None, None
         dw_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
-        call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, _s())
+        call("sbl_conv2d_wgrad", _p(x), _p(dconv), _p(dw_ohwi), NIMG, H, W, Cin, Cout, KH, KW, stride, pad, 0, _s())
         if gw is not None:
             call("sbl_conv_wgrad_unpack", _p(dw_ohwi), _p(gw), Cout, Cin, KH, KW, 1, _s())
             return dx, None, dgamma, dbeta, None, None, dres_ret, None, None, None, None, None, None, None, None, None

@@ -88,6 +88,8 @@ class Decoder(nn.Module):
         add <sos> / <eos>, pad both to 16 with *eos*.  Vectorised on the input's device, no host sync."""
         N, To = padded_input.shape
         maxlen = config.MAX_DECODE_LEN
+        if padded_input.is_cuda:
+            return self._preprocess_device(padded_input)
         valid = padded_input.ne(IGNORE_ID)
         # stable compaction of the valid ids to the left (the reference's y[y != IGNORE_ID])
         order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
@@ -103,6 +105,21 @@ class Decoder(nn.Module):
         ys_out_pad[:, :min(To, maxlen)] = comp[:, :maxlen]
         assert ys_in_pad.size() == ys_out_pad.size()
         return ys_in_pad, ys_out_pad
+
+    def _preprocess_device(self, a, b=None):
+        """preprocess on the GPU: one launch of sbl_decoder_preprocess for one target tensor or for both directions (instead
+        of ~20 torch launches each).  Returns (ys_in, ys_out) or (ys_in_a, ys_out_a, ys_in_b, ys_out_b)."""
+        maxlen = config.MAX_DECODE_LEN
+        a = a.contiguous().long()
+        N, To = a.shape
+        outs = [a.new_empty((N, maxlen)) for _ in range(4 if b is not None else 2)]
+        if b is not None:
+            b = b.contiguous().long()
+            assert b.shape == a.shape
+        ops.call("sbl_decoder_preprocess", a.data_ptr(), b.data_ptr() if b is not None else None, outs[0].data_ptr(),
+                 outs[1].data_ptr(), outs[2].data_ptr() if b is not None else None, outs[3].data_ptr() if b is not None else None,
+                 N, To, maxlen, self.sos_id, self.eos_id, IGNORE_ID, torch.cuda.current_stream(a.device).cuda_stream)
+        return tuple(outs)
 
     def _layers(self, direction):
         first = self.layer_first_l2r if direction == 0 else self.layer_first_r2l
@@ -224,8 +241,12 @@ class Decoder(nn.Module):
         Returns: (pred_l2r (N,16,58), gold_l2r (N,16), pred_r2l, gold_r2l)
         """
         dev = encoder_outputs.device
-        ys_in_pad_l2r, ys_out_pad_l2r = self.preprocess(padded_input_l2r.to(dev))
-        ys_in_pad_r2l, ys_out_pad_r2l = self.preprocess(padded_input_r2l.to(dev))
+        if dev.type == "cuda" and padded_input_l2r.shape == padded_input_r2l.shape:
+            ys_in_pad_l2r, ys_out_pad_l2r, ys_in_pad_r2l, ys_out_pad_r2l = self._preprocess_device(
+                padded_input_l2r.to(dev), padded_input_r2l.to(dev))
+        else:
+            ys_in_pad_l2r, ys_out_pad_l2r = self.preprocess(padded_input_l2r.to(dev))
+            ys_in_pad_r2l, ys_out_pad_r2l = self.preprocess(padded_input_r2l.to(dev))
         if decoder_stages.supported(self, encoder_outputs):
             # same coins, same order as _run / decoder.py:176
             if self.coins_host is not None:

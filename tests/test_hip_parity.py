@@ -217,7 +217,7 @@ def test_conv2d_fwd_dgrad_wgrad(ops, NIMG, H, W, Cin, Cout, k, stride):
     assert maxdiff(dxd, _nhwc(x.grad)) < 4e-7 * (Cout * k * k) ** 0.5 * 4
     dwd = torch.empty(Cout, k, k, Cin, device=DEV)
     ops.call("sbl_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), NIMG, H, W, Cin, Cout, k, k, stride, pad,
-             ops._s())
+             0, ops._s())
     dw = torch.empty(Cout, Cin, k, k, device=DEV)
     ops.call("sbl_conv_wgrad_unpack", dwd.data_ptr(), dw.data_ptr(), Cout, Cin, k, k, 0, ops._s())
     assert relerr(dw, w.grad) < 2e-5      # split-K float atomics over NIMG*Ho*Wo pixels
@@ -242,7 +242,7 @@ def test_dgrad_epilogue_reduces_the_next_batchnorm_backward(ops, NIMG, H, W, C, 
     ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx0.data_ptr(), NIMG, H, W, C, Cout, 3, 3, 1, 1, ws.data_ptr(), ops.WS_BYTES, ops._s())
     sums = torch.full((2 * C,), float("nan"), device=DEV, dtype=torch.float64)
     ops.call("sbl_conv2d_dgrad_bnstats", dy.data_ptr(), w_dg.data_ptr(), dx1.data_ptr(), NIMG, H, W, C, Cout, 3, 3, 1, 1, ws.data_ptr(),
-             ops.WS_BYTES, act.data_ptr(), pre.data_ptr(), mean.data_ptr(), inv.data_ptr(), sums.data_ptr(), ops._s())
+             ops.WS_BYTES, act.data_ptr(), pre.data_ptr(), mean.data_ptr(), inv.data_ptr(), sums.data_ptr(), 0, ops._s())
     assert torch.equal(dx0, dx1)
     ref = torch.empty(2 * C, device=DEV, dtype=torch.float64)
     ops.call("sbl_bn_bwd_reduce", dx0.data_ptr(), act.data_ptr(), pre.data_ptr(), mean.data_ptr(), inv.data_ptr(), ref.data_ptr(),
@@ -566,6 +566,31 @@ def test_batched_teacher_runs_equal_per_step_schedule(ops):
     for n, g in res[0][3].items():
         if n.startswith("decoder") or n.startswith("encoder"):
             assert maxdiff(g, res[1][3][n]) < 1e-3 * float(res[1][3][n].abs().max()) + 2e-6, n
+
+
+def test_decoder_preprocess_kernel_equals_torch_path():
+    """sbl_decoder_preprocess (one launch, both directions) against the vectorised torch form of Decoder.preprocess, which the
+    CPU suite pins to the reference's golden (tests/test_abi_cpu.py): ragged targets, rows of IGNORE_ID only, IGNORE_ID in the
+    middle, targets longer than MAX_DECODE_LEN - 1."""
+    from sbl_for_multilingual_lip_reading_amd import config
+    from sbl_for_multilingual_lip_reading_amd.transformer.decoder import Decoder
+    dec = Decoder(0, 1, 58, 512, 1, 8, 64, 64, 512, 2048)
+    g = torch.Generator().manual_seed(3)
+    for N, To in ((32, 12), (5, 15), (7, 16), (3, 20), (1, 1)):
+        a = torch.randint(2, config.vocab_size, (N, To), generator=g)
+        b = torch.randint(2, config.vocab_size, (N, To), generator=g)
+        lens = torch.randint(0, To + 1, (N,), generator=g)
+        for t, shift in ((a, 0), (b, 1)):
+            for n in range(N):
+                t[n, int(lens[(n + shift) % N]):] = config.IGNORE_ID
+        if To > 3:
+            a[0, 1] = config.IGNORE_ID          # a hole inside the sequence: the reference's y[y != IGNORE_ID] closes it
+        ref = dec.preprocess(a) + dec.preprocess(b)                          # CPU tensors: the torch path
+        got = dec._preprocess_device(a.to(DEV), b.to(DEV))
+        single = dec.preprocess(a.to(DEV))
+        for r, o in zip(ref, got):
+            assert torch.equal(r, o.cpu())
+        assert torch.equal(single[0].cpu(), ref[0]) and torch.equal(single[1].cpu(), ref[1])
 
 
 def test_loss_golden(ops, golden_modules):

@@ -32,5 +32,5 @@ for name, H, Cin, Cout, k, stride in [("layer1", 22, 64, 64, 3, 1), ("layer2", 1
         ops.set_matmul_precision(prec)
         t1 = timeit(lambda: ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), sp, 0, NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
         t2 = timeit(lambda: ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._workspace().data_ptr(), ops.WS_BYTES, ops._s()))
-        t3 = timeit(lambda: ops.call("sbl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, ops._s()))
+        t3 = timeit(lambda: ops.call("sbl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), NIMG, H, H, Cin, Cout, k, k, stride, pad, 0, ops._s()))
         print("%-8s %-6s %5.1f GF  fwd %7.1f us (%5.1f TF)  dgrad %7.1f us (%5.1f TF)  wgrad %7.1f us (%5.1f TF)" % (name, prec, fl / 1e3, t1, fl / t1, t2, fl / t2, t3, fl / t3), flush=True)

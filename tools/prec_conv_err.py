@@ -30,7 +30,7 @@ for (NIMG, H, W, Cin, Cout, k, stride) in shapes:
         dxd = torch.empty_like(xd)
         ops.call("sbl_conv2d_dgrad", dyd.data_ptr(), w_dg.data_ptr(), dxd.data_ptr(), NIMG, H, W, Cin, Cout, k, k, stride, pad, ws.data_ptr(), ops.WS_BYTES, ops._s())
         dwd = torch.empty(Cout, k, k, Cin, device=DEV)
-        ops.call("sbl_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), NIMG, H, W, Cin, Cout, k, k, stride, pad, ops._s())
+        ops.call("sbl_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), NIMG, H, W, Cin, Cout, k, k, stride, pad, 0, ops._s())
         def rel(a, b): return float((a.cpu().double() - b).abs().max() / b.abs().max())
         line += " %s fwd %.1e dg %.1e wg %.1e |" % (mode, rel(yd, nhwc(y.detach())), rel(dxd, nhwc(x.grad)), rel(dwd, w.grad.permute(0, 2, 3, 1)))
     print(line, flush=True)
