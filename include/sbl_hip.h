@@ -132,6 +132,13 @@ int sbl_bn_eval_stats(const float* running_mean, const float* running_var, float
 /* y = [relu]( gamma*(x-mean)*invstd + beta [+ res] ), NHWC rows x C */
 int sbl_bn_apply_fwd(const float* x, const float* res, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, float* y, long rows, int C, int relu, sbl_stream_t stream);
+/* Training form: sbl_bn_finalize folded into the apply launch - mean / invstd are derived from the convolution epilogue's
+ * (sum, sumsq) statistics inside the kernel (same double arithmetic), save_mean / save_invstd, the running statistics and
+ * num_batches_tracked are written by the same launch.  C/4 must divide 256. */
+int sbl_bn_apply_fwd_stats(const float* x, const float* res, const double* stats, long count, float* running_mean,
+                           float* running_var, float momentum, float eps, const float* gamma, const float* beta, float* y,
+                           float* save_mean, float* save_invstd, int64_t* num_batches_tracked, long rows, int C, int relu,
+                           sbl_stream_t stream);
 /* sums = double[2C] (sum g, sum g*xhat), g = dy * (y>0 if relu); overwritten by the call.
  * ws: NULL or the calling stream's sbl_gemm_f32 workspace (>= 16 KiB of int counters that are zero between launches,
  * then fp32 scratch): block partials + a last-arriver reduction replace 2C contended double atomics per block. */

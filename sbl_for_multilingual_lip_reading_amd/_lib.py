@@ -22,6 +22,7 @@ SIGNATURES = {
     "sbl_bn_finalize": [P, L, P, P, F, F, P, P, I, P, P],
     "sbl_bn_eval_stats": [P, P, F, P, P, I, P],
     "sbl_bn_apply_fwd": [P, P, P, P, P, P, P, L, I, I, P],
+    "sbl_bn_apply_fwd_stats": [P, P, P, L, P, P, F, F, P, P, P, P, P, P, L, I, I, P],
     "sbl_bn_bwd_reduce": [P, P, P, P, P, P, L, I, I, P, L, P],
     "sbl_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "sbl_conv_weight_pack": [P, P, P, I, I, I, I, P, I, P],

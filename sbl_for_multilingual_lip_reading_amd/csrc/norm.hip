@@ -32,6 +32,59 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
     }
 }
 
+// Training form with the BatchNorm "finalize" folded in: every thread keeps one channel quad for its whole grid-stride walk
+// (the stride is a multiple of C/4, which divides 256), so it derives that quad's mean / invstd once from the (sum, sumsq)
+// statistics of the producing convolution's epilogue - in double, exactly as bn_finalize_kernel does - and the first C/4
+// threads of the grid also write what the separate launch wrote: save_mean / save_invstd for backward, the running
+// statistics (momentum update, unbiased variance) and num_batches_tracked.  One launch per BatchNorm less (19 per step).
+__global__ __launch_bounds__(256) void bn_apply_fwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                 const double* __restrict__ stats, long count,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float momentum, float eps, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ y,
+                                                                 float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                 long long* __restrict__ nbt, long n4, int C4, int relu) {
+    const long i0 = blockIdx.x * 256L + threadIdx.x;
+    const int c = (int)(i0 % C4) * 4, C = C4 * 4;
+    float mu[4], is[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double mean = stats[c + q] / (double)count;
+        double var = stats[C + c + q] / (double)count - mean * mean;
+        if (var < 0) var = 0;
+        mu[q] = (float)mean;
+        is[q] = (float)(1.0 / sqrt(var + (double)eps));
+        if (i0 < C4) {
+            save_mean[c + q] = mu[q];
+            save_invstd[c + q] = is[q];
+            if (running_mean) {
+                const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+                running_mean[c + q] = (float)((1.0 - momentum) * running_mean[c + q] + momentum * mean);
+                running_var[c + q] = (float)((1.0 - momentum) * running_var[c + q] + momentum * unbiased);
+            }
+        }
+    }
+    if (i0 == 0 && nbt) *nbt += 1;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    for (long i = i0; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 o;
+        o.x = (v.x - mu[0]) * is[0] * ga.x + be.x;
+        o.y = (v.y - mu[1]) * is[1] * ga.y + be.y;
+        o.z = (v.z - mu[2]) * is[2] * ga.z + be.z;
+        o.w = (v.w - mu[3]) * is[3] * ga.w + be.w;
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
 // backward pass 1: per-channel sum g and sum g*xhat, g = dy * (y > 0 if relu).
 // A thread keeps one channel quad for its whole grid-stride walk (stride is a multiple of C4).
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -219,6 +272,23 @@ extern "C" int sbl_bn_apply_fwd(const float* x, const float* res, const float* m
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, res, mean, invstd,
                        gamma, beta, y, n4, C / 4, relu);
     SBL_LAUNCH_CHECK("sbl_bn_apply_fwd");
+    return 0;
+}
+
+extern "C" int sbl_bn_apply_fwd_stats(const float* x, const float* res, const double* stats, long count, float* running_mean,
+                                      float* running_var, float momentum, float eps, const float* gamma, const float* beta,
+                                      float* y, float* save_mean, float* save_invstd, int64_t* num_batches_tracked, long rows,
+                                      int C, int relu, sbl_stream_t stream) {
+    SBL_REQUIRE(x && stats && gamma && beta && y && save_mean && save_invstd && rows > 0 && count > 0 && C >= 4 && C % 4 == 0,
+                "sbl_bn_apply_fwd_stats: bad args rows=%ld C=%d", rows, C);
+    SBL_REQUIRE((C / 4) <= 256 && 256 % (C / 4) == 0, "sbl_bn_apply_fwd_stats: C=%d unsupported (C/4 must divide 256)", C);
+    SBL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "sbl_bn_apply_fwd_stats: running stats must both be set or both null");
+    SBL_REQUIRE(sbl_aligned16(x) && sbl_aligned16(y) && (!res || sbl_aligned16(res)), "sbl_bn_apply_fwd_stats: unaligned");
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_fwd_stats_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, res, stats, count,
+                       running_mean, running_var, momentum, eps, gamma, beta, y, save_mean, save_invstd,
+                       (long long*)num_batches_tracked, n4, C / 4, relu);
+    SBL_LAUNCH_CHECK("sbl_bn_apply_fwd_stats");
     return 0;
 }
 

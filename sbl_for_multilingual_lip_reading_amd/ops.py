@@ -1058,25 +1058,28 @@ class ConvBNFn(torch.autograd.Function):
         w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
         # the input-gradient layout [Cin][kh][kw][Cout] is packed by the same launch and kept for backward
         w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if (training and ctx.needs_input_grad[0]) else None
-        # (the pack launch also zeroes the BN statistics the convolution's epilogue accumulates into)
+        # (the pack launch also zeroes the BN statistics the convolution's epilogue accumulates into.  Measured and not kept:
+        # all 19 packs on the side stream while the stem runs - same-box A/B 32.94 vs 32.72 ms, the fork/join and the
+        # contention with the stem cost more than the 10 us per convolution they take off the chain)
         stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64) if training else None
         call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _p(stats), 2 * Cout if training else 0, _s())
         conv = torch.empty(NIMG, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         mean = torch.empty(Cout, device=dev, dtype=torch.float32)
         invstd = torch.empty(Cout, device=dev, dtype=torch.float32)
+        y = torch.empty_like(conv)
+        r = None if res is None else res.contiguous()
         if training:
             call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), _p(stats), 1, NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                  _workspace().data_ptr(), WS_BYTES, _s())
-            call("sbl_bn_finalize", _p(stats), NIMG * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps, _p(mean),
-                 _p(invstd), Cout, _p(nbt), _s())
+            # the BatchNorm "finalize" (mean / invstd / running statistics / num_batches_tracked) rides on the apply launch
+            call("sbl_bn_apply_fwd_stats", _p(conv), _p(r), _p(stats), NIMG * Ho * Wo, _p(running_mean), _p(running_var), momentum, eps,
+                 _p(gamma), _p(beta), _p(y), _p(mean), _p(invstd), _p(nbt), NIMG * Ho * Wo, Cout, int(relu), _s())
         else:
             call("sbl_conv2d_fwd", _p(x), _p(w_ohwi), _p(conv), None, 0, NIMG, H, W, Cin, Cout, KH, KW, stride, pad,
                  _workspace().data_ptr(), WS_BYTES, _s())
             call("sbl_bn_eval_stats", _p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), Cout, _s())
-        y = torch.empty_like(conv)
-        r = None if res is None else res.contiguous()
-        call("sbl_bn_apply_fwd", _p(conv), _p(r), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), NIMG * Ho * Wo, Cout,
-             int(relu), _s())
+            call("sbl_bn_apply_fwd", _p(conv), _p(r), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), NIMG * Ho * Wo, Cout,
+                 int(relu), _s())
         ctx.save_for_backward(x, w, conv, y if relu else None, mean, invstd, gamma, w_dg)
         ctx.cfg = (relu, stride, pad, training, res is not None)
         ctx.gb_bn = (_gbuf(gamma), _gbuf(beta))

@@ -1340,12 +1340,12 @@ def test_full_size_step_properties(ops):
 
     l1, g1, p1 = run(True)
     l2, g2, p2 = run(False)
-    assert abs(l1 - l2) < 1e-5 and maxdiff(p1, p2) < 1e-4
+    assert abs(l1 - l2) < 2e-5 and maxdiff(p1, p2) < 1e-4       # (a loss of 9.4: 2e-5 is 20 ulp; BN statistics are float-atomic sums)
     # transformer gradients agree to fp32 summation order; the frontend's pass through 17 train-mode BatchNorms (the
     # conditioning noted in DESIGN.md), so its bound is looser
     assert rel(g1, g2, "decoder.") < 1e-4 and rel(g1, g2, "encoder.") < 1e-3 and rel(g1, g2, "visual_frontend.") < 2e-2
     l3, g3, _ = run(True, scale=2.0)
-    assert abs(l3 - l1) < 1e-5          # BN statistics are reduced with atomics: the forward repeats to a few ulp
+    assert abs(l3 - l1) < 2e-5          # BN statistics are reduced with atomics: the forward repeats to a few ulp
     assert rel(g3, 2 * g1, "decoder.") < 1e-5 and rel(g3, 2 * g1, "encoder.") < 1e-4 and rel(g3, 2 * g1, "visual_frontend.") < 2e-2
     assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
 
