@@ -39,18 +39,18 @@ def neutralise_dropout(model):
     F.dropout = lambda x, p=0.5, training=True, inplace=False: x
 
 
-def det_load(model, salt=0):
+def det_load(model, salt=0, gains=None):
     sd = model.state_dict()
     new = {}
     for k, v in sd.items():
         if k.endswith(".pe"):
             new[k] = v
         else:
-            new[k] = torch.from_numpy(detfill.fill_value(k, tuple(v.shape), salt).copy())
+            new[k] = torch.from_numpy(detfill.fill_value(k, tuple(v.shape), salt, gains).copy())
     model.load_state_dict(new)
 
 
-def build_sbl(n_enc, n_dec):
+def build_sbl(n_enc, n_dec, gains=None):
     from transformer.decoder import Decoder
     from transformer.encoder import Encoder
     from transformer.transformer import Transformer
@@ -58,8 +58,19 @@ def build_sbl(n_enc, n_dec):
     dec = Decoder(0, 1, 58, 512, n_dec, 8, 64, 64, 512, 2048)
     m = Transformer(enc, dec, None)
     neutralise_dropout(m)
-    det_load(m)
+    det_load(m, gains=gains)
     return m
+
+
+def assert_varied(tag, ids_by_dir, margins):
+    """The fixture must exercise the token feedback loop (decoder.py:166-186): >= 6 distinct arg-max ids per direction, no
+    two samples with the same id sequence, every arg-max margin > 1e-2 (so a 1e-3-accurate evaluation picks the same ids)."""
+    for d, ids in ids_by_dir.items():
+        ids = np.asarray(ids)
+        assert len(set(ids.flatten().tolist())) >= 6, (tag, d, ids)
+        rows = [tuple(r) for r in ids.tolist()]
+        assert len(set(rows)) == len(rows), (tag, d, "two samples decode alike")
+    assert float(np.min(margins)) > 1e-2, (tag, float(np.min(margins)))
 
 
 FULL_GRADS = [
@@ -75,10 +86,10 @@ FULL_GRADS = [
 ]
 
 
-def e2e(tag, B, T, H, W, n_enc, n_dec, coin_seed, salt):
+def e2e(tag, B, T, H, W, n_enc, n_dec, coin_seed, salt, gains=None):
     """Train-mode forward + loss + backward of Transformer (SBL/train.py:188-196)."""
     from transformer.loss import cal_performance
-    m = build_sbl(n_enc, n_dec)
+    m = build_sbl(n_enc, n_dec, gains)
     m.train()
     x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, salt)
     random.seed(coin_seed)
@@ -120,24 +131,53 @@ def e2e(tag, B, T, H, W, n_enc, n_dec, coin_seed, salt):
               "visual_frontend.resnet18.layer2.0.downsample.1.running_var"):
         out["after:" + k] = sd[k].numpy()
     out["after:nbt"] = sd["visual_frontend.frontend3D.1.num_batches_tracked"].numpy()
+    if gains is not None:
+        out["gains"] = np.array(gains)
+        assert_varied(tag, {"l2r": out["argmax_l2r"], "r2l": out["argmax_r2l"]}, [out["margin_l2r"].min(), out["margin_r2l"].min()])
     np.savez_compressed(os.path.join(OUT, "e2e_%s.npz" % tag), **out)
     print("e2e", tag, "loss", loss.item(), "min margin", float(min(out["margin_l2r"].min(), out["margin_r2l"].min())))
 
 
-def eval_recognize(tag, B, T, H, W, n_enc, n_dec, salt):
-    """Eval-mode (running-stat BN) forward and greedy decode (SBL/test.py:174)."""
-    m = build_sbl(n_enc, n_dec)
-    m.eval()
+def eval_recognize(tag, B, T, H, W, n_enc, n_dec, salt, gains=None, train_bn=False):
+    """Greedy decode, Transformer.recognize (transformer.py:45-69, SBL/test.py:174).  Default: eval mode (running-stat
+    BN).  train_bn=True runs the same reference method with the module in train() mode (batch-statistics BatchNorm, every
+    dropout p = 0): with the deterministic running statistics the encoder output is nearly the same for every sample, in
+    train mode the samples differ, and so do their greedy token sequences."""
+    m = build_sbl(n_enc, n_dec, gains)
+    m.train() if train_bn else m.eval()
     x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, salt)
-    grabbed = {}
+    grabbed = {"logits": []}
     m.visual_frontend.register_forward_hook(lambda mod, i, o: grabbed.__setitem__("feats", o.detach().clone()))
     m.encoder.register_forward_hook(lambda mod, i, o: grabbed.__setitem__("enc", o[0].detach().clone()))
+    for head in (m.decoder.tgt_word_prj_l2r, m.decoder.tgt_word_prj_r2l):      # arg-max margins of every greedy step
+        head.register_forward_hook(lambda mod, i, o: grabbed["logits"].append(o.detach().clone()))
     with torch.no_grad():
         ys_l, ys_r = m.recognize(torch.from_numpy(x))
+    margins = []
+    for lg in grabbed["logits"]:
+        top = lg.reshape(-1, lg.size(-1)).topk(2, -1).values
+        margins.append(float((top[:, 0] - top[:, 1]).min()))
+    extra = {}
+    if gains is not None:
+        extra["gains"] = np.array(gains)
+        assert_varied(tag, {"l2r": ys_l.numpy()[:, 1:], "r2l": ys_r.numpy()[:, 1:]}, margins)
     np.savez_compressed(os.path.join(OUT, "recognize_%s.npz" % tag), B=B, T=T, H=H, W=W, n_enc=n_enc,
                         n_dec=n_dec, salt=salt, feats=grabbed["feats"].numpy(), enc=grabbed["enc"].numpy(),
-                        ys_l2r=ys_l.numpy(), ys_r2l=ys_r.numpy())
-    print("recognize", tag, ys_l[0].tolist())
+                        ys_l2r=ys_l.numpy(), ys_r2l=ys_r.numpy(), min_margin=min(margins), train_bn=int(train_bn), **extra)
+    print("recognize", tag, ys_l[0].tolist(), "min margin", min(margins))
+
+
+def state_dict_keys():
+    """The reference model's own state-dict surface (537 keys, shapes, dtypes): the drop-in contract of SURVEY 3.5 / 8b."""
+    m = build_sbl(6, 6)
+    sd = m.state_dict()
+    keys = sorted(sd.keys())
+    np.savez_compressed(os.path.join(OUT, "state_dict_keys.npz"), keys=np.array(keys),
+                        shapes=np.array([",".join(str(d) for d in sd[k].shape) for k in keys]),
+                        dtypes=np.array([str(sd[k].dtype) for k in keys]),
+                        param_names=np.array([n for n, _ in m.named_parameters()]),
+                        buffer_names=np.array([n for n, _ in m.named_buffers()]))
+    print("state_dict_keys", len(keys))
 
 
 def modules():
@@ -316,3 +356,9 @@ if __name__ == "__main__":
     if args.only in ("", "rec"):
         eval_recognize("full", 2, 29, 88, 88, 6, 6, salt=7)
         eval_recognize("small", 2, 8, 24, 24, 2, 2, salt=5)
+    # fixtures whose arg-max ids vary over steps, samples and directions (they exercise the token feedback loop)
+    if args.only in ("", "varied"):
+        e2e("varied", 3, 29, 88, 88, 6, 6, coin_seed=13, salt=34, gains="varied")
+        eval_recognize("varied", 3, 29, 88, 88, 6, 6, salt=34, gains="varied", train_bn=True)
+    if args.only in ("", "keys"):
+        state_dict_keys()

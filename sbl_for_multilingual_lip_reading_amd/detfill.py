@@ -50,7 +50,27 @@ def normal(name: str, shape, salt: int = 0) -> np.ndarray:
     return z.astype(np.float32)
 
 
-def fill_value(name: str, shape, salt: int = 0) -> np.ndarray:
+# Named sets of per-tensor gains (substring of the state-dict key -> factor) applied on top of the rules of fill_value.
+# "varied": with the plain fill the residual stream of the randomly initialised decoder is dominated by a component that
+# is the same for every position and sample (12 near-uniform attention averages), so every logit row has the same arg-max and
+# the token feedback loop (decoder.py:166-186) never changes what is fed.  A strong token embedding and weak sub-layer output
+# projections keep the stream token-dominated: arg-max ids then differ across steps, samples and directions.
+GAIN_SETS = {"varied": {"tgt_word_emb": 30.0, "attn.fc.weight": 0.3, "w_2.weight": 0.3}}
+
+
+def _gain(name: str, gains) -> float:
+    if not gains:
+        return 1.0
+    if isinstance(gains, str):
+        gains = GAIN_SETS[gains]
+    g = 1.0
+    for pat, f in gains.items():
+        if pat in name:
+            g *= f
+    return g
+
+
+def fill_value(name: str, shape, salt: int = 0, gains=None) -> np.ndarray:
     """Value for one state-dict entry of the SBL model (any of its 537 keys).
 
     Rules (by key suffix / rank), chosen so train-mode BatchNorm and LayerNorm
@@ -70,7 +90,7 @@ def fill_value(name: str, shape, salt: int = 0) -> np.ndarray:
         rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
         fan_in, fan_out = shape[1] * rf, shape[0] * rf
         bound = np.sqrt(6.0 / (fan_in + fan_out))
-        return (u * np.float32(bound)).astype(np.float32)
+        return (u * np.float32(bound * _gain(name, gains))).astype(np.float32)
     if name.endswith("running_var"):
         return (1.0 + 0.25 * np.abs(u)).astype(np.float32)
     if name.endswith("running_mean"):
@@ -80,14 +100,14 @@ def fill_value(name: str, shape, salt: int = 0) -> np.ndarray:
     return (0.05 * u).astype(np.float32)
 
 
-def fill_state_dict(shapes: dict, salt: int = 0) -> dict:
+def fill_state_dict(shapes: dict, salt: int = 0, gains=None) -> dict:
     """{name: shape} -> {name: np.ndarray}; 'pe' buffers are skipped (they are
     computed, not learned: SBL/transformer/module.py:17-24)."""
     out = {}
     for name, shape in shapes.items():
         if name.endswith(".pe"):
             continue
-        out[name] = fill_value(name, shape, salt)
+        out[name] = fill_value(name, shape, salt, gains)
     return out
 
 

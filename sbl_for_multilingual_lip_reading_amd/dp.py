@@ -84,16 +84,33 @@ class FlatModel:
                     off += pad(n)
                 self.ranges[seg] = (start, off)
         self.numel = total
+        self.device_index = dev.index if dev.type == "cuda" else None
+        self._in_backward = False
+        _ops().register_flat_model(self)
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def begin_backward(self):
+        """Called by the FIRST tape node of every backward (ops._backward_enter; every sbl autograd Function's backward
+        goes through it), i.e. before any kernel of that backward has accumulated into the flat gradient: this is the only
+        point where a dropped `.grad` may be turned into a zeroed slice.  The reference loop zeroes between forward and
+        backward (SBL/train.py:195-196: forward, optimizer.zero_grad(), loss.backward()), so the tape nodes' forward-time
+        view of the buffers must stay valid and nothing may be zeroed once accumulation is under way."""
+        self._in_backward = True
+        torch.autograd.Variable._execution_engine.queue_callback(self._end_backward)
+        if any(p.grad is not p._sbl_grad for p, _, _ in self.slots):
+            self.reattach()
+
+    def _end_backward(self):
+        self._in_backward = False
 
     def reattach(self):
         """Repair after a foreign `zero_grad(set_to_none=True)` (torch.optim's default) or an assignment to `p.grad`: the
         kernels accumulate into the flat gradient whatever `p.grad` says, so a parameter whose `.grad` was dropped gets
         its slice zeroed (= the fresh gradient the caller asked for) and `.grad` pointed back at it; an assigned foreign
-        gradient is copied into the slice first.  Called by ops._gbuf from the first tape node of a backward that finds
-        a detached parameter, i.e. before any kernel of that backward has accumulated."""
+        gradient is copied into the slice first.  Runs at the root of a backward (begin_backward), never after a kernel of
+        that backward has accumulated."""
         dropped = [(p, off) for p, off, _ in self.slots if p.grad is None]
         with torch.no_grad():
             if len(dropped) == len(self.slots):
@@ -203,8 +220,16 @@ class GradientExchange:
             dist.all_reduce(b, op=dist.ReduceOp.SUM)
             self.launches.append((seg, b.numel()))
 
-    def launch(self, seg):
-        if self.world <= 1 or seg in self._pending:
+    def launch(self, seg, _from_finish=False):
+        if self.world <= 1:
+            return
+        if seg in self._pending:
+            if not _from_finish:
+                # a second backward reached this segment before finish(): its first micro-batch was already averaged in
+                # place, so accumulating on top of it would silently diverge the ranks
+                raise RuntimeError("GradientExchange: segment %r was already exchanged in this step; call finish() after "
+                                   "every backward (for gradient accumulation build the exchange with overlap=False and "
+                                   "call finish() once after the last micro-batch)" % seg)
             return
         g = self.flat.segment_grad(seg)
         self._pending.append(seg)
@@ -229,7 +254,7 @@ class GradientExchange:
         if self.world <= 1:
             return
         for seg in FlatModel.SEGMENTS:
-            self.launch(seg)
+            self.launch(seg, _from_finish=True)
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending = []

@@ -382,17 +382,41 @@ def _gbuf(p):
     """The persistent gradient buffer of a parameter, if the model was flattened (dp.FlatModel): backward then
     accumulates into it inside the kernels (GEMM epilogue '+=', atomics) and returns None to autograd, instead of
     allocating a gradient and having AccumulateGrad add it with a separate kernel (16x per decoder parameter).
-    If the caller dropped or replaced `p.grad` since (torch.optim's zero_grad(set_to_none=True) default), the flat model
-    re-attaches every parameter first (dp.FlatModel.reattach), so `p.grad` always IS the buffer the kernels write."""
+    The buffer is the parameter's fixed slice of the flat gradient whatever `p.grad` currently says; a `.grad` the caller
+    dropped or replaced (torch.optim's zero_grad(set_to_none=True) default, possibly BETWEEN forward and backward as in
+    SBL/train.py:195-196) is repaired once, at the root of the next backward (_backward_enter)."""
     if p is None:
         return None
-    g = getattr(p, "_sbl_grad", None)
-    if g is None:
-        return None
-    if p.grad is None or p.grad.data_ptr() != g.data_ptr():
-        p._sbl_flat.reattach()
-        g = p._sbl_grad
-    return g
+    return getattr(p, "_sbl_grad", None)
+
+
+import functools as _functools
+import weakref as _weakref
+
+_flat_models = _weakref.WeakSet()
+
+
+def register_flat_model(fm):
+    _flat_models.add(fm)
+
+
+def _backward_enter():
+    """First thing every sbl tape node's backward does: the first node of a backward pass lets each flat model of this
+    device repair / zero detached gradients BEFORE any kernel accumulates (dp.FlatModel.begin_backward)."""
+    if not _flat_models:
+        return
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    for fm in list(_flat_models):
+        if not fm._in_backward and fm.device_index in (None, dev):
+            fm.begin_backward()
+
+
+def _bw(fn):
+    @_functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        _backward_enter()
+        return fn(ctx, *grads)
+    return wrapped
 
 
 def _target(buf, shape, dev, zero=False):
@@ -424,6 +448,7 @@ class LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
@@ -472,6 +497,7 @@ class DropoutFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
@@ -496,6 +522,7 @@ class AddPEFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         return dy, None
 
@@ -521,6 +548,7 @@ class AddLayerNormFn(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         x2, r2, gamma, mean, rstd = ctx.saved_tensors
         D = x2.size(1)
@@ -551,6 +579,7 @@ class RowScaleFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         (sc,) = ctx.saved_tensors
         dy = dy.contiguous()
@@ -605,6 +634,7 @@ class SDPAFn(torch.autograd.Function):
         return o, p
 
     @staticmethod
+    @_bw
     def backward(ctx, do, _dp):
         if do is None:
             return (None,) * 8
@@ -653,6 +683,7 @@ class KVProjectFn(torch.autograd.Function):
         return kv
 
     @staticmethod
+    @_bw
     def backward(ctx, dkv):
         x2, wk, wv = ctx.saved_tensors
         dkv = dkv.contiguous()
@@ -740,6 +771,7 @@ class MHAFn(torch.autograd.Function):
         return y, p
 
     @staticmethod
+    @_bw
     def backward(ctx, dy, _dp):
         if dy is None:
             return (None,) * 19
@@ -798,6 +830,11 @@ class MHAFn(torch.autograd.Function):
         return (dx, dkv, dwq_ret, dbq_ret, None, None, None, None, dwfc_ret, dbfc_ret, dgamma_ret, dbeta_ret) + (None,) * 7
 
 
+# tests only: callable(w1, h) handed every feed-forward's post-ReLU hidden activation (tests/test_hip_parity.py compares the
+# ReLU masks of this path and of the CPU oracle, to tell a flipped mask bit from an arithmetic error)
+_ffn_probe = None
+
+
 class FFNFn(torch.autograd.Function):
     """PositionwiseFeedForward.forward (module.py:47-52) as one tape node:
     LayerNorm(dropout(relu(x W1^T + b1) W2^T + b2) + x); dropout fused into the LayerNorm kernels."""
@@ -811,6 +848,8 @@ class FFNFn(torch.autograd.Function):
         M, F_, dev = x2.size(0), w1.size(0), x.device
         h = torch.empty(M, F_, device=dev, dtype=torch.float32)
         gemm(0, 1, M, F_, D, x2, D, w1, D, h, F_, bias=b1, relu=1)
+        if _ffn_probe is not None:
+            _ffn_probe(w1, h)
         o = torch.empty(M, D, device=dev, dtype=torch.float32)
         gemm(0, 1, M, D, F_, h, F_, w2, F_, o, D, bias=b2)
         seed, off = None, 0
@@ -829,6 +868,7 @@ class FFNFn(torch.autograd.Function):
         return y.view(shp)
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         x2, h, o, mean, rstd, w1, w2, gamma, seed = ctx.saved_tensors
         shp, drop_p, off = ctx.cfg
@@ -881,6 +921,7 @@ class EmbedPEFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         V, D = ctx.shape
         dy = dy.contiguous()
@@ -908,6 +949,7 @@ class FusionFn(torch.autograd.Function):
         return a2, b2
 
     @staticmethod
+    @_bw
     def backward(ctx, da2, db2):
         B, segL, D = ctx.cfg
         da2, db2 = da2.contiguous(), db2.contiguous()
@@ -932,6 +974,7 @@ class GatherLastFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         B, segL, D, shp = ctx.cfg
         dy = dy.contiguous()
@@ -970,6 +1013,7 @@ class SmoothedCEFn(torch.autograd.Function):
         return out3[0] / out3[1], out3
 
     @staticmethod
+    @_bw
     def backward(ctx, gloss, _g3):
         if gloss is None:
             return None, None, None, None
@@ -1018,6 +1062,7 @@ class StemFn(torch.autograd.Function):
         return pooled
 
     @staticmethod
+    @_bw
     def backward(ctx, dpooled):
         x, conv, argmax, mean, invstd, gamma, beta = ctx.saved_tensors
         if not ctx.training:
@@ -1091,18 +1136,21 @@ class ConvBNFn(torch.autograd.Function):
         ctx.ctl = ctl if training else None
         if ctx.ctl is not None:
             if ctl["role"] == "conv2":
-                ctl["pub"].update(conv=conv, mean=mean, invstd=invstd, act=y)
+                # (only the address of the activation is kept: the dict hangs on y itself (`y._sbl_pub`), a tensor in it
+                # would be a reference cycle that only the cyclic GC frees - ~1 GB of trunk activations per step)
+                ctl["pub"].update(conv=conv, mean=mean, invstd=invstd, act=y.data_ptr())
             elif ctl["role"] == "ds":
                 ctl["pub"].update(conv2=conv, mean2=mean, invstd2=invstd)
         if training:      # (grad mode is off inside Function.forward; backward only runs if a tape exists)
             if box_out is not None and relu and res is None:
-                box_out.update(conv=conv, mean=mean, invstd=invstd, act=y)
+                box_out.update(conv=conv, mean=mean, invstd=invstd, act=y.data_ptr())
                 ctx.box_out = box_out
-            if box_in is not None and stride == 1 and box_in.get("act") is not None and box_in["act"].data_ptr() == x.data_ptr():
+            if box_in is not None and stride == 1 and box_in.get("act") == x.data_ptr():
                 ctx.box_in = box_in
         return y
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         x, w, conv, y, mean, invstd, gamma, w_dg = ctx.saved_tensors
         relu, stride, pad, training, has_res = ctx.cfg
@@ -1126,6 +1174,7 @@ class ConvBNFn(torch.autograd.Function):
             sums = full[:2 * Cout]
             if full.numel() == 4 * Cout:
                 ctl["link"]["ds_sums"] = full[2 * Cout:]     # the downsample BatchNorm's pair: same g, its own xhat
+            pub.clear()                                       # consumed: drop the published tensors now
         elif role == "ds" and ctl["link"].get("ds_sums") is not None:
             sums = ctl["link"].pop("ds_sums")
         else:
@@ -1170,8 +1219,7 @@ class ConvBNFn(torch.autograd.Function):
                 addend = link.pop("dres", None) if link.get("identity") else link.pop("dx_ds", None)
                 link["main_done"] = True
                 prev = ctl.get("prev")
-                fuse = (prev is not None and addend is not None and prev.get("act") is not None
-                        and prev["act"].data_ptr() == x.data_ptr())
+                fuse = prev is not None and addend is not None and prev.get("act") == x.data_ptr()
                 nsums = None
                 if fuse:
                     two = prev.get("conv2") is not None
@@ -1240,6 +1288,7 @@ class AvgPoolFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bw
     def backward(ctx, dy):
         NIMG, H, W, C = ctx.shape
         dy = dy.contiguous()

@@ -270,6 +270,7 @@ class DecoderStagesFn(torch.autograd.Function):
         return pred[0].view(ML, N, V).transpose(0, 1), pred[1].view(ML, N, V).transpose(0, 1)
 
     @staticmethod
+    @ops._bw
     def backward(ctx, dpl, dpr):
         S = ctx.state
         call, gemm, segs = ops.call, ops.gemm, ops._segs

@@ -54,7 +54,8 @@ class BasicBlock(nn.Module):
             residual = x
         y = _conv_bn(out, self.conv2, self.bn2, residual, True, self.training, box_in=box,
                      ctl={"role": "conv2", "link": link, "pub": pub})
-        y._sbl_pub = pub
+        if self.training and torch.is_grad_enabled():
+            y._sbl_pub = pub
         return y
 
 

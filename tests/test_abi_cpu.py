@@ -7,6 +7,8 @@ import subprocess
 import sys
 
 import pytest
+
+from conftest import load_golden
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,6 +77,14 @@ def test_state_dict_surface_matches_reference():
     shapes = O.state_dict_shapes(6, 6)
     got = {k: tuple(v.shape) for k, v in sd.items() if not k.endswith(".pe")}
     assert got == {k: tuple(v) for k, v in shapes.items()}
+    # ... and against the REFERENCE's own model (tests/golden/state_dict_keys.npz, written by oracle/make_goldens.py from
+    # /root/reference): every key, shape and dtype, parameters and buffers alike, in the reference's registration order
+    ref = load_golden("state_dict_keys.npz")
+    assert sorted(sd.keys()) == [str(k) for k in ref["keys"]]
+    for k, shp, dt in zip(ref["keys"], ref["shapes"], ref["dtypes"]):
+        assert ",".join(str(d) for d in sd[str(k)].shape) == str(shp) and str(sd[str(k)].dtype) == str(dt), str(k)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in ref["param_names"]]
+    assert [n for n, _ in m.named_buffers()] == [str(n) for n in ref["buffer_names"]]
     assert tuple(sd["encoder.positional_encoding.pe"].shape) == (1, 5000, 512)
     # q/k/v projection weights are adjacent rows of one fused buffer after _fuse()
     mha = m.encoder.layer_stack[0].slf_attn

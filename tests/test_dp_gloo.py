@@ -5,6 +5,7 @@ which is exactly what the exchange sees after a real backward."""
 import os
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -54,7 +55,11 @@ def _worker(rank, world, port, overlap, q):
         assert len(ex._hooks) == 5                   # encoder out, frontend out, inputs of ResNet stages 4, 3, 2
         for seg in dp.FlatModel.SEGMENTS[:-1]:
             ex.launch(seg)
-        ex.launch("decoder.")                        # idempotent within a step
+        try:                                         # a second backward before finish() is refused, not swallowed
+            ex.launch("decoder.")
+            raise AssertionError("second launch of an exchanged segment must raise")
+        except RuntimeError as e:
+            assert "finish()" in str(e)
     ex.finish()
     # reverse-autograd order, <= 1 MB each, every element exactly once
     order = [s for s, _ in ex.launches]
@@ -96,3 +101,20 @@ def test_dp_overlap_hooks_world2():
 
 def test_dp_sum_mode_world2():
     _run("sum", 29613)
+
+
+def test_gradient_exchange_refuses_second_backward_before_finish():
+    """a segment already exchanged (averaged in place) must not silently swallow a second backward."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+
+    class _F:      # the two members launch() touches
+        flat_grad = torch.zeros(8)
+        def segment_grad(self, seg):
+            return self.flat_grad[:0]
+    ex = dp.GradientExchange.__new__(dp.GradientExchange)
+    ex.flat, ex.world, ex._pending, ex.cuda = _F(), 2, [], False
+    ex.launch("decoder.")
+    with pytest.raises(RuntimeError, match="finish"):
+        ex.launch("decoder.")
+    ex.finish()
+    ex.launch("decoder.")

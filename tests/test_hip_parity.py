@@ -31,6 +31,20 @@ def ops(request):
     _ops.set_matmul_precision("f32")
 
 
+@pytest.fixture(autouse=True)
+def _pin_precision(request):
+    """Tests that do not take the `ops` fixture run under the library default ("f32"), whatever mode the previous
+    module-scoped parametrisation left active (the precision is a process-wide setting of the tile engine)."""
+    if "ops" not in request.fixturenames:
+        from sbl_for_multilingual_lip_reading_amd import ops as _ops
+        prev = _ops.get_matmul_precision()
+        _ops.set_matmul_precision("f32")
+        yield
+        _ops.set_matmul_precision(prev)
+    else:
+        yield
+
+
 def U(name, shape, s=1.0):
     return torch.from_numpy(detfill.uniform(name, shape) * np.float32(s))
 
@@ -426,9 +440,9 @@ def test_sdpa_module_golden(ops, golden_modules):
     assert maxdiff(o, g["sdpa.causal_out"]) < 5e-6 and maxdiff(a, g["sdpa.causal_attn"]) < 2e-6
 
 
-def _load_det(module, prefix=""):
+def _load_det(module, prefix="", gains=None):
     sd = module.state_dict()
-    module.load_state_dict({k: (v if k.endswith("pe") else torch.from_numpy(detfill.fill_value(prefix + k, tuple(v.shape)).copy()))
+    module.load_state_dict({k: (v if k.endswith("pe") else torch.from_numpy(detfill.fill_value(prefix + k, tuple(v.shape), 0, gains).copy()))
                             for k, v in sd.items()})
     for mm in module.modules():
         if isinstance(mm, torch.nn.Dropout):
@@ -773,23 +787,122 @@ def test_frontend_small_golden(ops, golden_modules):
         assert maxdiff(fe(x), g["fe.eval_out"]) < 1e-4
 
 
-def build_model(n_enc, n_dec):
+def build_model(n_enc, n_dec, gains=None):
     from sbl_for_multilingual_lip_reading_amd.transformer.decoder import Decoder
     from sbl_for_multilingual_lip_reading_amd.transformer.encoder import Encoder
     from sbl_for_multilingual_lip_reading_amd.transformer.transformer import Transformer
     m = Transformer(Encoder(512, n_enc, 8, 64, 64, 512, 2048), Decoder(0, 1, 58, 512, n_dec, 8, 64, 64, 512, 2048), None)
-    _load_det(m)
+    _load_det(m, gains=gains)
     m.visual_frontend.frontend_dropout_p = 0.0
     return m.to(DEV)
 
 
-@pytest.mark.parametrize("tag", ["small", "full"])
+# --------------------------------------------------------------------------- #
+# gradient parity with ReLU-mask bookkeeping
+# --------------------------------------------------------------------------- #
+class _FFNMasks:
+    """Records the ReLU mask (h > 0) of every feed-forward call of the HIP path (ops._ffn_probe) and of the CPU oracle
+    (wrapped O.ffn), keyed by the FFN's parameter prefix, rows in call order (both paths run the decoder's steps in the
+    same order: segment-major, batch-major inside a segment)."""
+
+    def __init__(self, ops_mod, model, oracle_mod):
+        self.ops, self.O = ops_mod, oracle_mod
+        self.name_of = {p.data_ptr(): n[:-len(".w_1.weight")] for n, p in model.named_parameters() if n.endswith(".w_1.weight")}
+        self.hip, self.ref = {}, {}
+
+    def __enter__(self):
+        O = self.O
+        self._ffn = O.ffn
+
+        def ffn(sd, prefix, x, drop=0.0):
+            h = torch.relu(torch.nn.functional.linear(x, sd[prefix + ".w_1.weight"], sd[prefix + ".w_1.bias"]))
+            self.ref.setdefault(prefix, []).append((h.detach() > 0).reshape(-1, h.size(-1)))
+            return self._ffn(sd, prefix, x, drop)
+        O.ffn = ffn
+        self.ops._ffn_probe = lambda w1, h: self.hip.setdefault(self.name_of[w1.data_ptr()], []).append((h.detach() > 0).cpu())
+        return self
+
+    def __exit__(self, *exc):
+        self.O.ffn = self._ffn
+        self.ops._ffn_probe = None
+
+    def flips(self):
+        """[(ffn prefix, hidden unit, rows that differ)] - hidden units whose mask differs anywhere between the two paths."""
+        out = []
+        assert sorted(self.hip) == sorted(self.ref), (sorted(self.hip), sorted(self.ref))
+        for k in sorted(self.hip):
+            a, b = torch.cat(self.hip[k], 0), torch.cat(self.ref[k], 0)
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            d = (a != b)
+            for u in d.any(0).nonzero().flatten().tolist():
+                out.append((k, u, int(d[:, u].sum())))
+        return out
+
+
+def _upstream_of(prefix, n_dec_layers):
+    """Parameter-name prefixes whose gradients a changed ReLU mask bit inside FFN `prefix` reaches (everything that feeds
+    that FFN's input): for an encoder layer n the attention of layer n, layers < n and linear_in / layer_norm_in; for a
+    decoder layer n of either direction the attentions of that layer, every lower layer of BOTH directions (the SBL fusion
+    mixes them, decoder.py:127-143), the embedding, and the whole encoder and frontend."""
+    lay = prefix[:-len(".pos_ffn")]
+    if lay.startswith("encoder.layer_stack."):
+        n = int(lay.split(".")[2])
+        ups = ["encoder.layer_stack.%d.slf_attn" % n] + ["encoder.layer_stack.%d." % i for i in range(n)]
+        return ups + ["encoder.linear_in", "encoder.layer_norm_in", "visual_frontend."]
+    if "layer_first" in lay:
+        n = 0
+    else:
+        n = int(lay.split(".")[2]) + 1
+    ups = [lay + ".slf_attn", lay + ".enc_attn", "decoder.tgt_word_emb", "encoder.", "visual_frontend."]
+    for i in range(n):
+        for d in ("l2r", "r2l"):
+            ups.append("decoder.layer_first_%s." % d if i == 0 else "decoder.layer_stack_%s.%d." % (d, i - 1))
+    return ups
+
+
+def check_transformer_grads(named, ref_sd, flips, n_dec, skip=()):
+    """Element-wise 2e-3 * max + 2e-6 on every encoder / decoder gradient.  A ReLU mask bit that differs between the two
+    fp32-grade evaluations (pre-activation within rounding of 0; listed in `flips`, at most 3 tolerated) legitimately
+    moves row u of that FFN's dW1 / db1 and column u of its dW2 by O(1/rows): exactly those rows / columns are excluded, and
+    the tensors upstream of that FFN get the measured loose bound (5e-2 * max, 5e-3 relative L2) instead."""
+    assert len(flips) <= 3, flips
+    if flips:
+        print("ReLU mask flips (ffn, hidden unit, rows):", flips)
+    loose = [u for f in flips for u in _upstream_of(f[0], n_dec)]
+    worst = (0.0, None)
+    for n, p in named.items():
+        if not (n.startswith("decoder") or n.startswith("encoder")) or n in skip:
+            continue
+        r = ref_sd[n].grad
+        g = p.grad.detach().cpu()
+        keep = torch.ones_like(r, dtype=torch.bool)
+        for k, u, _ in flips:
+            if n in (k + ".w_1.weight", k + ".w_1.bias"):
+                keep[u] = False
+            elif n == k + ".w_2.weight":
+                keep[:, u] = False
+        scale = float(r.abs().max())
+        if any(n.startswith(u) for u in loose):
+            assert float((g - r).norm()) < 5e-3 * float(r.norm()) + 1e-5, n
+            assert maxdiff(g, r) < 5e-2 * scale + 2e-6, n
+            continue
+        err = float(((g - r).abs() * keep).max())
+        if scale > 0 and err / scale > worst[0]:
+            worst = (err / scale, n)
+        assert err < 2e-3 * scale + 2e-6, (n, err, scale)
+    print("worst element-wise gradient error / max|ref|: %.2e (%s)" % worst)
+
+
+
+@pytest.mark.parametrize("tag", ["small", "full", "varied"])
 def test_e2e_train_step_golden(ops, tag):
-    """Transformer.forward + loss + backward (SBL/train.py:188-196) against the REFERENCE's outputs."""
+    """Transformer.forward + loss + backward (SBL/train.py:188-196) against the REFERENCE's outputs.  "varied": B = 3, 6+6
+    layers, weights scaled so that the arg-max ids fed back differ over steps, samples and directions (>= 6 distinct per
+    direction, margins > 1e-2): a wrong sample's or a wrong step's arg-max changes what the later steps compute."""
     from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
     g = load_golden("e2e_%s.npz" % tag)
     B, T, H, W = int(g["B"]), int(g["T"]), int(g["H"]), int(g["W"])
-    m = build_model(int(g["n_enc"]), int(g["n_dec"])).train()
+    m = build_model(int(g["n_enc"]), int(g["n_dec"]), str(g["gains"]) if "gains" in g.files else None).train()
     x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, int(g["salt"]))
     feats = {}
     m.visual_frontend.register_forward_hook(lambda mod, i, o: feats.__setitem__("feats", o.detach()))
@@ -839,31 +952,26 @@ def test_e2e_matches_oracle_other_seed(ops):
     B, T, H, W, ne, nd = 3, 5, 40, 24, 1, 2
     x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 21)
     sd = O.make_state_dict(ne, nd, requires_grad=True)
-    random.seed(5)
-    coins = O.draw_coins()
-    ref = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins, ne, nd)
-    rloss = O.train_step_loss(ref)
-    rloss.backward()
     m = build_model(ne, nd).train()
-    random.seed(5)
-    pl, gl, pr, gr = m(torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV))
+    masks = _FFNMasks(ops, m, O)
+    with masks:
+        random.seed(5)
+        coins = O.draw_coins()
+        ref = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins, ne, nd)
+        rloss = O.train_step_loss(ref)
+        rloss.backward()
+        random.seed(5)
+        pl, gl, pr, gr = m(torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV))
     loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
     loss.backward()
     assert maxdiff(pl, ref["pred_l2r"]) < 1e-3 and maxdiff(pr, ref["pred_r2l"]) < 1e-3
     assert abs(loss.item() - rloss.item()) < 1e-3
-    # Gradients: ReLU's derivative jumps at 0, and of the ~3e6 feed-forward pre-activations of this step a few lie within
-    # rounding distance of 0 (density ~1 per unit => ~1 within 3e-7).  Any two fp32-grade evaluations can therefore
-    # disagree on one mask bit, which moves ONE row of that layer's dW1 / db1 by O(1/rows) (2.4e-2 of max observed for
-    # hidden unit 1779 of layer_stack_r2l.0 between the two MFMA modes on this input, everything else of that tensor
-    # equal) and everything upstream of it by ~1e-3.  Hence a per-tensor relative L2 bound plus a loose max bound
-    # here; the reference fixtures (test_e2e_train_step_golden) carry the tight element-wise gradient checks.
-    named = dict(m.named_parameters())
-    for n, p in named.items():
-        if n.startswith("decoder") or n.startswith("encoder"):
-            r = sd[n].grad
-            g = p.grad.detach().cpu()
-            assert float((g - r).norm()) < 5e-3 * float(r.norm()) + 1e-5, n
-            assert maxdiff(g, r) < 5e-2 * float(r.abs().max()) + 2e-6, n
+    # Gradients, element-wise 2e-3 * max for f32 and bf16x6 alike.  ReLU's derivative jumps at 0, and of the ~3e6
+    # feed-forward pre-activations of this step a few lie within rounding distance of 0, so two fp32-grade evaluations can
+    # disagree on one mask bit (seen once: hidden unit 1779 of layer_stack_r2l.0 under bf16x6).  The masks of both paths are
+    # compared; a differing unit is NAMED, at most 3 are tolerated, and only its rows / columns (and, loosely, the tensors
+    # upstream of it) are exempt - see check_transformer_grads.
+    check_transformer_grads(dict(m.named_parameters()), sd, masks.flips(), nd)
 
 
 def test_config5_shape_matches_oracle(ops):
@@ -875,26 +983,23 @@ def test_config5_shape_matches_oracle(ops):
     B, T, H, W, ne, nd = 2, 64, 112, 112, 1, 1
     x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 23)
     sd = O.make_state_dict(ne, nd, requires_grad=True)
-    random.seed(9)
-    coins = O.draw_coins()
-    ref = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins, ne, nd)
-    rloss = O.train_step_loss(ref)
-    rloss.backward()
     m = build_model(ne, nd).train()
-    random.seed(9)
-    pl, gl, pr, gr = m(torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV))
+    masks = _FFNMasks(ops, m, O)
+    with masks:
+        random.seed(9)
+        coins = O.draw_coins()
+        ref = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins, ne, nd)
+        rloss = O.train_step_loss(ref)
+        rloss.backward()
+        random.seed(9)
+        pl, gl, pr, gr = m(torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV))
     loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
     loss.backward()
     assert maxdiff(pl, ref["pred_l2r"]) < 1e-3 and maxdiff(pr, ref["pred_r2l"]) < 1e-3      # north-star bar
     assert abs(loss.item() - rloss.item()) < 1e-3
-    # relative L2 per tensor: with 557 k ReLU pre-activations per FFN a unit sitting within rounding of zero can
-    # switch sides between two fp32 summation orders, which moves ONE row of dW1 / one column of dW2 by a finite
-    # amount (seen here: max-abs 1.7 % on one row, L2 unaffected); element-wise bounds are kept at the other sizes
-    for n, p in m.named_parameters():
-        if (n.startswith("decoder") or n.startswith("encoder")) and not n.endswith("w_ks.bias"):
-            r = sd[n].grad
-            rel = float((p.grad.detach().cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-30))
-            assert rel < 5e-3, (n, rel)
+    # element-wise gradient bound with the ReLU-mask bookkeeping of check_transformer_grads (557 k pre-activations per FFN
+    # here: a unit within rounding of zero can switch sides, which is named and exempted, nothing else is)
+    check_transformer_grads(dict(m.named_parameters()), sd, masks.flips(), nd)      # (K-bias gradients are analytically 0: the absolute floor covers them)
 
 
 @pytest.mark.parametrize("B,two", [(16, True), (3, True), (4, False)])
@@ -1178,10 +1283,66 @@ def test_flat_model_with_torch_adam_and_default_zero_grad(ops):
     for n, p in m1.named_parameters():
         if (n.startswith("decoder") or n.startswith("encoder")) and p.dim() >= 2:
             assert float((p - p2[n]).norm()) < 1e-2 * float(p2[n].norm()) + 1e-6, n       # (bound: see the test above)
-    # an assigned foreign gradient is adopted, not lost
+    # an assigned foreign gradient is adopted (copied into the flat slice), not lost
     w = m1.encoder.linear_in.weight
     w.grad = torch.full_like(w, 3.0)
+    f1.reattach()
     assert ops._gbuf(w).data_ptr() == w.grad.data_ptr() and float(w._sbl_grad.mean()) == 3.0
+
+
+@pytest.mark.parametrize("freeze_frontend", [False, True])
+def test_flat_model_reference_loop_order_zero_grad_between_forward_and_backward(ops, freeze_frontend):
+    """The reference's loop order (SBL/train.py:195-196): forward, THEN optimizer.zero_grad() (torch default
+    set_to_none=True), then loss.backward(), step().  Every tape node took its view of the flat gradient buffer in forward;
+    the dropped `.grad`s must be zeroed and re-attached ONCE at the root of backward - never by a later node, which would
+    wipe the decoder / encoder gradients accumulated before it (and with a frozen frontend no convolution node runs at
+    all).  Checked against the FusedAdam path, which zeroes before forward."""
+    from sbl_for_multilingual_lip_reading_amd import dp
+    from sbl_for_multilingual_lip_reading_amd.transformer.loss import cal_performance_device
+    from sbl_for_multilingual_lip_reading_amd.transformer.optimizer import FusedAdam, TransformerOptimizer
+    B, T, H, W, ne, nd = 2, 4, 24, 24, 1, 1
+    x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, 52)
+    xd, ld, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(l2r).to(DEV), torch.from_numpy(r2l).to(DEV)
+    m1, m2 = build_model(ne, nd).train(), build_model(ne, nd).train()
+    m1.decoder.coins_host = m2.decoder.coins_host = [False] * 16
+    if freeze_frontend:
+        for m in (m1, m2):
+            for p in m.visual_frontend.parameters():
+                p.requires_grad = False
+    f1, f2 = dp.FlatModel(m1), dp.FlatModel(m2)
+    opt1 = torch.optim.Adam([p for p in m1.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.98), eps=1e-09)
+    opt2 = TransformerOptimizer(FusedAdam(f2, betas=(0.9, 0.98), eps=1e-09), warmup_steps=2, k=0.5)
+    grads = []
+    for step in range(2):
+        random.seed(300 + step)
+        pl, gl, pr, gr = m1(xd, ld, rd)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        opt1.zero_grad()                      # between forward and backward: every trainable p.grad is None now
+        assert m1.decoder.tgt_word_prj_l2r.weight.grad is None
+        loss.backward()
+        ops.join_side_streams()
+        g1 = f1.flat_grad.clone()
+        random.seed(300 + step)
+        opt2.zero_grad()
+        pl, gl, pr, gr = m2(xd, ld, rd)
+        loss = 0.5 * (cal_performance_device(pl, gl, 0.1)[0] + cal_performance_device(pr, gr, 0.1)[0])
+        loss.backward()
+        ops.join_side_streams()
+        g2 = f2.flat_grad.clone()
+        for seg in ("decoder.", "encoder."):
+            a, b = f1.ranges[seg]
+            assert float(g2[a:b].abs().max()) > 0
+            # one step's gradient, not two (nothing left over from the previous step) and not zero (nothing wiped)
+            assert float((g1[a:b] - g2[a:b]).norm()) <= 1e-3 * float(g2[a:b].norm()), (seg, step)
+        assert all(p.grad is not None and p.grad.data_ptr() == p._sbl_grad.data_ptr() for p in m1.parameters() if p.requires_grad)
+        # both models take the same (FusedAdam) step so that step 2 starts from equal weights
+        with torch.no_grad():
+            f1.flat_param.copy_(f2.flat_param)
+        opt2.step()
+        with torch.no_grad():
+            f1.flat_param.copy_(f2.flat_param)
+        grads.append(g1)
+    assert float((grads[0] - grads[1]).abs().max()) > 0        # the second step really was a different gradient
 
 
 def test_frozen_encoder_stage_is_honoured(ops):
@@ -1215,10 +1376,13 @@ def test_frozen_encoder_stage_is_honoured(ops):
     assert moved["visual_frontend.frontend3D.0.weight"] > 0.0 and moved["visual_frontend.resnet18.layer4.1.conv2.weight"] > 0.0
 
 
-@pytest.mark.parametrize("tag", ["small", "full"])
+@pytest.mark.parametrize("tag", ["small", "full", "varied"])
 def test_recognize_golden(ops, tag):
+    """Transformer.recognize against the reference's greedy ids.  "varied" (train-mode BatchNorm, scaled weights): 10 / 6
+    distinct ids per direction, every sample decodes differently, min margin 1.5e-2."""
     g = load_golden("recognize_%s.npz" % tag)
-    m = build_model(int(g["n_enc"]), int(g["n_dec"])).eval()
+    m = build_model(int(g["n_enc"]), int(g["n_dec"]), str(g["gains"]) if "gains" in g.files else None)
+    m = m.train() if ("train_bn" in g.files and int(g["train_bn"])) else m.eval()
     x, _, _ = detfill.synthetic_batch(int(g["B"]), int(g["T"]), int(g["H"]), int(g["W"]), int(g["salt"]))
     feats = {}
     m.visual_frontend.register_forward_hook(lambda mod, i, o: feats.__setitem__("feats", o.detach()))
@@ -1275,6 +1439,24 @@ def test_encoder_ragged_lengths(ops):
         h = h * npm
         h = O.ffn(sd, p + ".pos_ffn", h) * npm
     assert maxdiff(out, h) < 1e-4
+
+
+def test_encoder_return_attns(ops):
+    """Encoder.forward(..., return_attns=True) (encoder.py:36,65-67): (enc_output, [attn per layer]), attn laid out
+    (n_head * N, T, T) head-major like MultiHeadAttention returns it (attention.py:45-54,60), at the encoder's T = 29."""
+    from oracle import sbl_oracle as O
+    from sbl_for_multilingual_lip_reading_amd.transformer.encoder import Encoder
+    enc = _load_det(Encoder(512, 2, 8, 64, 64, 512, 2048), "encoder.").to(DEV).eval()
+    x = U("attns.x", (3, 29, 512))
+    out, attns = enc(x.to(DEV), [29, 29, 29], return_attns=True)
+    plain, = enc(x.to(DEV), [29, 29, 29])
+    sd = {k: torch.from_numpy(v.copy()) for k, v in detfill.fill_state_dict({k: v for k, v in O.state_dict_shapes(2, 1).items() if k.startswith("encoder.")}).items()}
+    ref, ref_attns = O.encoder(sd, x, 2, return_attns=True)
+    assert isinstance(attns, list) and len(attns) == 2 and torch.equal(out, plain)
+    assert maxdiff(out, ref) < 1e-4
+    for a, r in zip(attns, ref_attns):
+        assert tuple(a.shape) == (8 * 3, 29, 29) and maxdiff(a, r) < 1e-5
+        assert maxdiff(a.sum(-1), torch.ones(24, 29)) < 1e-5
 
 
 # --------------------------------------------------------------------------- size-independent properties at BASELINE sizes

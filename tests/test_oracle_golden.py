@@ -154,13 +154,29 @@ def test_noam_adam(golden_modules):
     assert maxdiff(p, g["opt.p_after3"]) < 1e-7
 
 
-@pytest.mark.parametrize("tag", ["small", "full"])
+def _gains(g):
+    return str(g["gains"]) if "gains" in g.files else None
+
+
+def _check_varied(ids_by_dir, min_margin):
+    """The "varied" fixtures exercise the token feedback loop: >= 6 distinct arg-max ids per direction,
+    no two samples alike, margins > 1e-2."""
+    for ids in ids_by_dir:
+        assert len(set(np.asarray(ids).flatten().tolist())) >= 6
+        rows = [tuple(r) for r in np.asarray(ids).tolist()]
+        assert len(set(rows)) == len(rows)
+    assert min_margin > 1e-2
+
+
+@pytest.mark.parametrize("tag", ["small", "full", "varied"])
 def test_e2e_train_step(tag):
     """Transformer.forward + loss + backward (SBL/train.py:188-196) vs the reference."""
     g = load_golden("e2e_%s.npz" % tag)
     B, T, H, W = int(g["B"]), int(g["T"]), int(g["H"]), int(g["W"])
     n_enc, n_dec = int(g["n_enc"]), int(g["n_dec"])
-    sd = O.make_state_dict(n_enc, n_dec, requires_grad=True)
+    sd = O.make_state_dict(n_enc, n_dec, requires_grad=True, gains=_gains(g))
+    if tag == "varied":
+        _check_varied((g["argmax_l2r"], g["argmax_r2l"]), min(float(g["margin_l2r"].min()), float(g["margin_r2l"].min())))
     x, l2r, r2l = detfill.synthetic_batch(B, T, H, W, int(g["salt"]))
     coins = [bool(c) for c in g["coins"]]
     out = O.transformer_forward(sd, torch.from_numpy(x), torch.from_numpy(l2r), torch.from_numpy(r2l), coins,
@@ -174,6 +190,7 @@ def test_e2e_train_step(tag):
     assert maxdiff(out["pred_l2r"], g["pred_l2r"]) < 2e-4
     assert maxdiff(out["pred_r2l"], g["pred_r2l"]) < 2e-4
     assert np.array_equal(out["pred_l2r"].argmax(-1).numpy(), g["argmax_l2r"])
+    assert np.array_equal(out["pred_r2l"].argmax(-1).numpy(), g["argmax_r2l"])
     assert abs(loss.item() - float(g["loss"])) < 2e-5
     names = [str(n) for n in g["grad_names"]]
     for n, ref in zip(names, g["grad_norms"]):
@@ -185,20 +202,26 @@ def test_e2e_train_step(tag):
             # frontend grads pass through 17 train-mode BatchNorms: fp32 reorder noise of ~1e-7 in
             # d(feats) is amplified to ~2e-3 of max at the stem (measured); K-bias grads are
             # analytically 0 (softmax shift invariance), hence the absolute floor.
-            assert maxdiff(sd[k[5:]].grad, ref) < 5e-3 * float(np.abs(ref).max()) + 1e-6, k
+            # ("varied": its decoder gradients are larger and rougher, and the same CPU-vs-CPU reorder noise reaches 5.6e-3 of
+            # max on the stem BatchNorm's bias - measured; transformer gradients keep the 5e-3 bound)
+            tol = 1e-2 if (tag == "varied" and k.startswith("grad:visual_frontend")) else 5e-3
+            assert maxdiff(sd[k[5:]].grad, ref) < tol * float(np.abs(ref).max()) + 1e-6, k
         if k.startswith("after:") and k != "after:nbt":
             assert maxdiff(sd[k[6:]], g[k]) < 1e-5, k
     assert int(sd["visual_frontend.frontend3D.1.num_batches_tracked"]) == int(g["after:nbt"])
 
 
-@pytest.mark.parametrize("tag", ["small", "full"])
+@pytest.mark.parametrize("tag", ["small", "full", "varied"])
 def test_recognize(tag):
     g = load_golden("recognize_%s.npz" % tag)
     n_enc, n_dec = int(g["n_enc"]), int(g["n_dec"])
-    sd = O.make_state_dict(n_enc, n_dec)
+    sd = O.make_state_dict(n_enc, n_dec, gains=_gains(g))
+    train_bn = bool(int(g["train_bn"])) if "train_bn" in g.files else False      # "varied": batch-statistics BatchNorm
+    if tag == "varied":
+        _check_varied((g["ys_l2r"][:, 1:], g["ys_r2l"][:, 1:]), float(g["min_margin"]))
     x, _, _ = detfill.synthetic_batch(int(g["B"]), int(g["T"]), int(g["H"]), int(g["W"]), int(g["salt"]))
     with torch.no_grad():
-        feats = O.frontend(sd, torch.from_numpy(x).unsqueeze(1), training=False)
+        feats = O.frontend(sd, torch.from_numpy(x).unsqueeze(1), training=train_bn)
         enc = O.encoder(sd, feats, n_enc)
         ys_l, ys_r = O.recognize_beam(sd, enc, n_dec)
     assert maxdiff(feats, g["feats"]) < 5e-5 and maxdiff(enc, g["enc"]) < 5e-5
