@@ -423,9 +423,14 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
                                                                   int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
                                                                   const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // SHARED_KV: [segment][dV | dK][32][64] partial tiles
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // SHARED_KV: [wavefront][dV | dK][32][64] partial tiles
     float* s_kv = s_dyn + (threadIdx.x >> 6) * 4096;                    // this wavefront's slice
-    const int prob = SHARED_KV ? (int)(threadIdx.x >> 6) * (B * H) + (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    // SHARED_KV: wavefront w handles segments w, w + nw, ... of this (batch, head) one after the other and sums their dK / dV
+    // tiles in its own LDS slice (up to 16 segments on 8 wavefronts: all 16 decoder steps in ONE launch, no second launch and
+    // no add kernel for the halves)
+    const int nwv = blockDim.x >> 6;
+  for (int sidx = (int)(threadIdx.x >> 6), pass = 0; pass == 0 || (SHARED_KV && sidx < segs.nseg); sidx += nwv, ++pass) {
+    const int prob = SHARED_KV ? sidx * (B * H) + (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (!SHARED_KV && prob >= nprob) return;
     const SmallProb P = small_prob(prob, B, H, segs, Lk_fixed);
     const int Lq = P.Lq, Lk = P.Lk;
@@ -571,8 +576,16 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
                     float* pv_ = dvb + (long)j * lddv + 4 * n;
                     float* pk_ = dkb + (long)j * lddk + 4 * n;
                     if (SHARED_KV) {      // (LDS float atomics into one shared image were measured 20 us slower at 5 segments)
-                        *reinterpret_cast<float4*>(&s_kv[j * 64 + 4 * n]) = make_float4(av[0][r], av[1][r], av[2][r], av[3][r]);
-                        *reinterpret_cast<float4*>(&s_kv[2048 + j * 64 + 4 * n]) = make_float4(ak[0][r], ak[1][r], ak[2][r], ak[3][r]);
+                        float4 a4 = make_float4(av[0][r], av[1][r], av[2][r], av[3][r]);
+                        float4 k4 = make_float4(ak[0][r], ak[1][r], ak[2][r], ak[3][r]);
+                        if (pass) {        // this lane wrote the same addresses in its previous pass
+                            const float4 pa = *reinterpret_cast<const float4*>(&s_kv[j * 64 + 4 * n]);
+                            const float4 pk = *reinterpret_cast<const float4*>(&s_kv[2048 + j * 64 + 4 * n]);
+                            a4.x += pa.x; a4.y += pa.y; a4.z += pa.z; a4.w += pa.w;
+                            k4.x += pk.x; k4.y += pk.y; k4.z += pk.z; k4.w += pk.w;
+                        }
+                        *reinterpret_cast<float4*>(&s_kv[j * 64 + 4 * n]) = a4;
+                        *reinterpret_cast<float4*>(&s_kv[2048 + j * 64 + 4 * n]) = k4;
                     } else if (kv_atomic) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -587,7 +600,12 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
             }
         }
     }
+  }
     if (SHARED_KV) {
+        const int Lk = Lk_fixed;
+        const int bb = ((int)blockIdx.x / H) % B, hh = (int)blockIdx.x % H;
+        float* dvb = dv + (long)bb * Lk * lddv + hh * 64;
+        float* dkb = dk + (long)bb * Lk * lddk + hh * 64;
         __syncthreads();
         const int nw = blockDim.x >> 6;
         for (int i = threadIdx.x; i < 2 * Lk * 16; i += blockDim.x) {
@@ -718,16 +736,18 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
         sbl_aligned16(dv)) {
         const int nprob = nseg * B * H;
         constexpr int shared_kv = 1;
-        if (Lk_fixed > 0 && nseg > 1 && !(shared_kv && nseg <= 8)) {      // atomics path accumulates: start from zero
+        if (Lk_fixed > 0 && nseg > 1 && !shared_kv) {      // atomics path accumulates: start from zero
             SBL_HIP(hipMemset2DAsync(dk, lddk * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
             SBL_HIP(hipMemset2DAsync(dv, lddv * sizeof(float), 0, (size_t)H * 64 * sizeof(float), (size_t)B * Lk_fixed, (hipStream_t)stream));
         }
-        if (shared_kv && Lk_fixed > 0 && nseg > 1 && nseg <= 8) {     // 8 wavefronts = 2 per SIMD at this kernel's register use
+        const int nwv = nseg < 8 ? nseg : 8;      // 8 wavefronts = 2 per SIMD at this kernel's register use; beyond 8 segments each
+                                                   // wavefront takes several (sbl_make_segs caps nseg at SBL_MAX_SEG = 16)
+        if (shared_kv && Lk_fixed > 0 && nseg > 1) {
             static bool attr_set2[64] = {false};
             if (int e = at_attr((const void*)attention_small_bwd_kernel<true>, 8 * 16384, attr_set2)) return e;
         }
-        if (shared_kv && Lk_fixed > 0 && nseg > 1 && nseg <= 8)
-            hipLaunchKernelGGL(attention_small_bwd_kernel<true>, dim3(B * H), dim3(64 * nseg), (size_t)nseg * 16384, (hipStream_t)stream, dout, lddo, q,
+        if (shared_kv && Lk_fixed > 0 && nseg > 1)
+            hipLaunchKernelGGL(attention_small_bwd_kernel<true>, dim3(B * H), dim3(64 * nwv), (size_t)nwv * 16384, (hipStream_t)stream, dout, lddo, q,
                                ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
                                drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
         else

@@ -13,13 +13,26 @@ import torch.distributed as dist
 
 
 def _ordered_params(model):
-    """Parameters in registration order, except that each MultiHeadAttention's (w_qs, w_ks, w_vs) weights and
-    biases are emitted as adjacent triples — the fused-QKV GEMM needs them to be rows of one matrix."""
+    """Parameters in registration order, except that
+      * each MultiHeadAttention's (w_qs, w_ks, w_vs) weights and biases are emitted as adjacent triples - the fused-QKV
+        GEMM needs them to be rows of one matrix;
+      * the cross-attention K/V projections of ALL decoder layers (l2r layers 0.., then r2l layers 0..; decoder.py:41-53)
+        are emitted as ONE block [w_ks_0; w_vs_0; w_ks_1; ...] (and one block of their biases): the K/V of the encoder
+        output for every layer and direction are then one (N*T, 12*1024) GEMM in forward, and their input gradient one
+        K = 12*1024 GEMM in backward (decoder_stages.py)."""
     from .transformer.attention import MultiHeadAttention
     seen, order = set(), []
     fused = []
+    cross = []
+    dec = getattr(model, "decoder", None)
+    if dec is not None and hasattr(dec, "_layers"):
+        cross = [lay.enc_attn for d in (0, 1) for lay in dec._layers(d)]
+    cross_ids = {id(m) for m in cross}
+    if cross:
+        fused.append([w for m in cross for w in (m.w_ks.weight, m.w_vs.weight)])
+        fused.append([b for m in cross for b in (m.w_ks.bias, m.w_vs.bias)])
     for mod in model.modules():
-        if isinstance(mod, MultiHeadAttention):
+        if isinstance(mod, MultiHeadAttention) and id(mod) not in cross_ids:
             fused.append([mod.w_qs.weight, mod.w_ks.weight, mod.w_vs.weight])
             fused.append([mod.w_qs.bias, mod.w_ks.bias, mod.w_vs.bias])
     lead = {id(g[0]): g for g in fused}

@@ -51,6 +51,12 @@ class MultiHeadAttention(nn.Module):
         bs = (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)
         if ops._adjacent(*ws) and ops._adjacent(*bs):
             return
+        if getattr(ws[0], "_sbl_flat", None) is not None:
+            # parameters of a dp.FlatModel are never re-allocated here.  Its layout keeps self-attention triples adjacent;
+            # the decoder's cross-attention modules have (w_ks, w_vs) adjacent inside the all-layers K/V block instead,
+            # which is all the cross-attention path (KVProjectFn / decoder_stages) needs
+            assert ops._adjacent(*ws[1:]) and ops._adjacent(*bs[1:]), "flat model: K/V projection weights are not adjacent"
+            return
         with torch.no_grad():
             fw = torch.cat([w.data for w in ws], 0).contiguous()
             fb = torch.cat([b.data for b in bs], 0).contiguous()

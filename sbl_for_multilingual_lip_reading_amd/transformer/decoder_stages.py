@@ -63,9 +63,11 @@ class _Layer:
         self.wq, self.bq, self.g_wq, self.g_bq = ea.w_qs.weight, ea.w_qs.bias, ops._gbuf(ea.w_qs.weight), ops._gbuf(ea.w_qs.bias)
         assert ops._adjacent(ea.w_ks.weight, ea.w_vs.weight) and ops._adjacent(ea.w_ks.bias, ea.w_vs.bias)
         self.wkv, self.bkv = ea.w_ks.weight, ea.w_ks.bias
+        self.wv_e, self.bv_e = ea.w_vs.weight, ea.w_vs.bias
         gkw, gkb = [ops._gbuf(t) for t in (ea.w_ks.weight, ea.w_vs.weight)], [ops._gbuf(t) for t in (ea.w_ks.bias, ea.w_vs.bias)]
         assert ops._adjacent(*gkw) and ops._adjacent(*gkb)
         self.g_wkv, self.g_bkv = gkw[0], gkb[0]
+        self.g_wv_e, self.g_bv_e = gkw[1], gkb[1]
         self.wfc_e, self.bfc_e, self.g_wfc_e, self.g_bfc_e = ea.fc.weight, ea.fc.bias, ops._gbuf(ea.fc.weight), ops._gbuf(ea.fc.bias)
         self.ln_e = (ea.layer_norm.weight, ea.layer_norm.bias, ops._gbuf(ea.layer_norm.weight), ops._gbuf(ea.layer_norm.bias), ea.layer_norm.eps)
         self.w1, self.b1, self.g_w1, self.g_b1 = ff.w_1.weight, ff.w_1.bias, ops._gbuf(ff.w_1.weight), ops._gbuf(ff.w_1.bias)
@@ -111,7 +113,7 @@ class DecoderStagesFn(torch.autograd.Function):
             for n in range(nl):
                 B_[d][n] = dict(x=E(R, D), qkv=E(R, 3 * HD), att=E(R, HD), ps=E(ps_off[ML]), o_s=E(R, D), mu_s=E(R), rs_s=E(R), y_s=E(R, D),
                                 q=E(R, HD), att2=E(R, HD), pe=E(pe_off[ML]), o_e=E(R, D), mu_e=E(R), rs_e=E(R), y_e=E(R, D),
-                                h=E(R, F_), o_f=E(R, D), mu_f=E(R), rs_f=E(R), y_f=E(R, D), kv=E(N * T, 2 * HD),
+                                h=E(R, F_), o_f=E(R, D), mu_f=E(R), rs_f=E(R), y_f=E(R, D), kv=None,
                                 off=[st.next_offset() for _ in range(5)] if training else [0] * 5)
         xout = [E(R, D), E(R, D)]
         x0 = [E(R, D) if p_emb > 0 else None for _ in (0, 1)]        # pre-dropout embeddings are not needed afterwards
@@ -126,15 +128,30 @@ class DecoderStagesFn(torch.autograd.Function):
             y[:, 0] = dec.sos_id
         seed = st.seed
 
-        # ---- hoisted cross-attention K/V: one launch per layer for both directions, or one GEMM per layer and direction
-        # with r2l on the side stream
+        # ---- hoisted cross-attention K/V (attention.py:42-43 for every layer and direction; step-invariant).  With the flat
+        # parameter layout of dp.FlatModel the 12 [W_k; W_v] pairs are rows of ONE (12*1024, 512) matrix: one GEMM writes
+        # KV_all (N*T, 12*1024), layer (d, n) reads its column block in place (row stride ldkv).  Otherwise one launch per
+        # layer for both directions, or one GEMM per layer and direction with r2l on the side stream.
         merged = getattr(dec, "merge_directions", True) and all(
             (layers[0][n].drop_s, layers[0][n].drop_e, layers[0][n].drop_f, layers[0][n].ln_s[4], layers[0][n].ln_e[4], layers[0][n].ln_f[4]) ==
             (layers[1][n].drop_s, layers[1][n].drop_e, layers[1][n].drop_f, layers[1][n].ln_s[4], layers[1][n].ln_e[4], layers[1][n].ln_f[4])
             for n in range(nl))
-        if merged:
+        kv_order = [layers[d][n] for d in (0, 1) for n in range(nl)]
+        kv_fused = (getattr(dec, "fuse_kv_projections", True)
+                    and ops._adjacent(*[w for L in kv_order for w in (L.wkv, L.wv_e)])
+                    and ops._adjacent(*[b for L in kv_order for b in (L.bkv, L.bv_e)])
+                    and ops._adjacent(*[g for L in kv_order for g in (L.g_wkv, L.g_wv_e)])
+                    and ops._adjacent(*[g for L in kv_order for g in (L.g_bkv, L.g_bv_e)]))
+        ldkv = 2 * HD * (2 * nl if kv_fused else 1)
+        if kv_fused:
+            kv_all = E(N * T, ldkv)
+            gemm(0, 1, N * T, ldkv, D, enc2, D, kv_order[0].wkv, D, kv_all, ldkv, bias=kv_order[0].bkv)
+            for i, (d, n) in enumerate((d, n) for d in (0, 1) for n in range(nl)):
+                B_[d][n]["kv"] = kv_all[:, i * 2 * HD:(i + 1) * 2 * HD]
+        elif merged:
             for n in range(nl):
                 L0, L1 = layers[0][n], layers[1][n]
+                B_[0][n]["kv"], B_[1][n]["kv"] = E(N * T, 2 * HD), E(N * T, 2 * HD)
                 ops.gemm2(N * T, 2 * HD, D, enc2, enc2, D, L0.wkv, L1.wkv, D, B_[0][n]["kv"], B_[1][n]["kv"], 2 * HD, L0.bkv, L1.bkv)
         else:
             if side is not None:
@@ -143,6 +160,7 @@ class DecoderStagesFn(torch.autograd.Function):
                 with torch.cuda.stream(streams[d]):
                     for n in range(nl):
                         L = layers[d][n]
+                        B_[d][n]["kv"] = E(N * T, 2 * HD)
                         gemm(0, 1, N * T, 2 * HD, D, enc2, D, L.wkv, D, B_[d][n]["kv"], 2 * HD, bias=L.bkv)
 
         # ---- stages (same rule as Decoder._run)
@@ -177,7 +195,7 @@ class DecoderStagesFn(torch.autograd.Function):
             y_s, q = b["y_s"][r0:r1], b["q"][r0:r1]
             gemm(0, 1, M, HD, D, y_s, D, L.wq, D, q, HD, bias=L.bq)
             kv = b["kv"]
-            call("sbl_attention_seg_fwd", _p(q), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD, _p(b["att2"][r0:r1]), HD,
+            call("sbl_attention_seg_fwd", _p(q), HD, _p(kv), ldkv, _p(kv[:, HD:]), ldkv, _p(b["att2"][r0:r1]), HD,
                  b["pe"].data_ptr() + 4 * pe_off[i0], 0, None, N, H, seg_arr, nseg, T, 0.125, L.drop_e,
                  _p(seed) if L.drop_e > 0 else None, _fold(b["off"][2], pe_off[i0]), ops._s())
             gemm(0, 1, M, D, HD, b["att2"][r0:r1], HD, L.wfc_e, HD, b["o_e"][r0:r1], D, bias=L.bfc_e)
@@ -218,7 +236,7 @@ class DecoderStagesFn(torch.autograd.Function):
             # cross-attention sub-layer
             ops.gemm2(M, HD, D, sl(b0, "y_s"), sl(b1, "y_s"), D, L0.wq, L1.wq, D, sl(b0, "q"), sl(b1, "q"), HD, L0.bq, L1.bq)
             kv0, kv1 = b0["kv"], b1["kv"]
-            call("sbl_attention_seg2_fwd", _p(sl(b0, "q")), _p(sl(b1, "q")), HD, _p(kv0), _p(kv1), 2 * HD, _p(kv0[:, HD:]), _p(kv1[:, HD:]), 2 * HD,
+            call("sbl_attention_seg2_fwd", _p(sl(b0, "q")), _p(sl(b1, "q")), HD, _p(kv0), _p(kv1), ldkv, _p(kv0[:, HD:]), _p(kv1[:, HD:]), ldkv,
                  _p(sl(b0, "att2")), _p(sl(b1, "att2")), HD, b0["pe"].data_ptr() + 4 * pe_off[i0], b1["pe"].data_ptr() + 4 * pe_off[i0],
                  0, N, H, seg_arr, nseg, T, 0.125, L0.drop_e, sp if L0.drop_e > 0 else None,
                  _fold(b0["off"][2], pe_off[i0]), _fold(b1["off"][2], pe_off[i0]), ops._s())
@@ -263,7 +281,8 @@ class DecoderStagesFn(torch.autograd.Function):
 
         ctx.state = dict(N=N, T=T, D=D, H=H, HD=HD, F=F_, V=V, ML=ML, nl=nl, R=R, layers=layers, B=B_, xout=xout, last=last, ys=ys,
                          heads=heads, g_heads=(ops._gbuf(heads[0]), ops._gbuf(heads[1])), g_emb=ops._gbuf(emb), seed=seed,
-                         p_emb=p_emb, off_emb=off_emb, streams=streams, two=side is not None, enc2=enc2, training=training)
+                         p_emb=p_emb, off_emb=off_emb, streams=streams, two=side is not None, enc2=enc2, training=training,
+                         kv_fused=kv_fused, ldkv=ldkv, kv_order=kv_order)
         ctx.set_materialize_grads(False)
         dec.last_ys = ys
         # (ML*N, V) step-major -> (N, ML, V) views
@@ -281,9 +300,10 @@ class DecoderStagesFn(torch.autograd.Function):
         seed = S["seed"]
         segL = tuple(range(1, ML + 1))
         seg_arr, nseg = segs(segL)
-        seg_lo, seg_hi = segs(segL[:8]), segs(segL[8:])
-        R8 = N * 36                                    # rows of the first 8 segments (prefix lengths 1..8)
-        pe8 = H * N * T * 36                           # their cross-attention probabilities
+        kv_fused, ldkv, kv_order = S["kv_fused"], S["ldkv"], S["kv_order"]
+        # gradient of the hoisted K/V: column block i = (direction, layer) of one (N*T, 12*1024) buffer when the projections
+        # are fused (its input gradient is then ONE product over K = 12*1024 below), else one buffer per layer and direction
+        dkv_all_buf = None
 
         def E(*shape):
             return torch.empty(*shape, device=dev, dtype=torch.float32)
@@ -337,15 +357,12 @@ class DecoderStagesFn(torch.autograd.Function):
             gemm(0, 0, R, HD, D, do2, D, L.wfc_e, HD, datt, HD)
             dq = E(R, HD)
             kv = b["kv"]
-            dkv_a, dkv_b = E(N * T, 2 * HD), E(N * T, 2 * HD)
-            # 16 segments share the keys: two launches of 8 (one workgroup per (batch, head) sums 8 segments in LDS)
-            for (arr, ns), r0, p0, dst in ((seg_lo, 0, 0, dkv_a), (seg_hi, R8, pe8, dkv_b)):
-                rows = slice(r0, R8 if r0 == 0 else R)
-                call("sbl_attention_seg_bwd", _p(datt[rows]), HD, _p(b["q"][rows]), HD, _p(kv), 2 * HD, _p(kv[:, HD:]), 2 * HD,
-                     b["pe"].data_ptr() + 4 * p0, _p(dq[rows]), HD, _p(dst), 2 * HD, _p(dst[:, HD:]), 2 * HD, N, H, arr, ns, T, 0.125,
-                     L.drop_e, _p(seed) if L.drop_e > 0 else None, _fold(b["off"][2], p0), ops._s())
-            dkv_a.add_(dkv_b)
-            dkv_all[d][n] = dkv_a
+            dkv = dkv_all_buf[:, (d * nl + n) * 2 * HD:(d * nl + n + 1) * 2 * HD] if kv_fused else E(N * T, 2 * HD)
+            # the 16 segments share the keys: one workgroup per (batch, head) sums their dK / dV contributions in LDS
+            call("sbl_attention_seg_bwd", _p(datt), HD, _p(b["q"]), HD, _p(kv), ldkv, _p(kv[:, HD:]), ldkv, _p(b["pe"]), _p(dq), HD,
+                 _p(dkv), ldkv, _p(dkv[:, HD:]), ldkv, N, H, seg_arr, nseg, T, 0.125, L.drop_e,
+                 _p(seed) if L.drop_e > 0 else None, b["off"][2], ops._s())
+            dkv_all[d][n] = dkv
             dW(L.g_wq, L.g_bq, dq, HD, b["y_s"], D, HD, D)
             gemm(0, 0, R, D, HD, dq, HD, L.wq, D, dz2, D, accumulate=1)
             keep.extend((do2, dq))
@@ -364,6 +381,8 @@ class DecoderStagesFn(torch.autograd.Function):
             keep.extend((do3, dqkv))
             return dz3
 
+        if kv_fused:
+            dkv_all_buf = E(N * T, ldkv)
         for n in range(nl - 1, -1, -1):
             if side is not None:
                 main.wait_stream(side)
@@ -375,7 +394,7 @@ class DecoderStagesFn(torch.autograd.Function):
                 with torch.cuda.stream(streams[d]):
                     dx[d] = layer_bwd(d, n, dy[d])
         # ---- embeddings (shared table: float atomics) and the hoisted K/V projections
-        denc = [E(N * T, D), E(N * T, D)]
+        denc = [E(N * T, D), None if kv_fused else E(N * T, D)]
         for d in (0, 1):
             with torch.cuda.stream(streams[d]):
                 g = dx[d]
@@ -384,18 +403,52 @@ class DecoderStagesFn(torch.autograd.Function):
                     call("sbl_dropout", _p(g), _p(g2), R * D, S["p_emb"], _p(seed), S["off_emb"][d], ops._s())
                     g = g2
                 call("sbl_embed_seg_bwd", _p(S["ys"][d]), S["ys"][d].stride(0), _p(g), _p(S["g_emb"]), N, seg_arr, nseg, D, V, ops._s())
-                for n in range(nl):
-                    L = layers[d][n]
-                    dkv = dkv_all[d][n]
-                    gemm(0, 0, N * T, D, 2 * HD, dkv, 2 * HD, L.wkv, D, denc[d], D, accumulate=1 if n else 0)
-                    wg.append((L.g_wkv, D, L.g_bkv, dkv, 2 * HD, S["enc2"], D, 2 * HD, D))   # rows = N*T: its own group
+                if not kv_fused:
+                    for n in range(nl):
+                        L = layers[d][n]
+                        dkv = dkv_all[d][n]
+                        gemm(0, 0, N * T, D, 2 * HD, dkv, 2 * HD, L.wkv, D, denc[d], D, accumulate=1 if n else 0)
+                        wg.append((L.g_wkv, D, L.g_bkv, dkv, 2 * HD, S["enc2"], D, 2 * HD, D))   # rows = N*T: its own group
         if side is not None:
             main.wait_stream(side)
-        denc[0].add_(denc[1])
+        if kv_fused:
+            # dEnc = [dKV_0 | ... | dKV_11] (N*T, 12*1024) x [Wkv_0; ...; Wkv_11] (12*1024, 512): ONE product instead of 12
+            # launches plus the adds of their partial results; its weight gradient is one (12*1024, 512) problem too
+            gemm(0, 0, N * T, D, ldkv, dkv_all_buf, ldkv, kv_order[0].wkv, D, denc[0], D)
+            wg.append((kv_order[0].g_wkv, D, kv_order[0].g_bkv, dkv_all_buf, ldkv, S["enc2"], D, ldkv, D))
+        else:
+            denc[0].add_(denc[1])
         # ---- every weight gradient of the decoder: one grouped launch per row count (R rows; N*T rows for K/V)
-        _flush_weight_grads(wg, {id(L.g_wkv): N * T for d in (0, 1) for L in layers[d]}, R, main, side)
+        _DeferredWeightGrads(wg, {id(L.g_wkv): N * T for d in (0, 1) for L in layers[d]}, R, main, side).arm()
         ctx.state = None
         return denc[0].view(N, T, D), None, None, None, None, None
+
+
+class _DeferredWeightGrads:
+    """The decoder's collected weight gradients, issued (grouped launches on the side stream) when backward has passed the
+    ENCODER: the encoder backward is a dependent chain of 928-row products that cannot fill the chip, and beside the
+    2688-tile grouped launch its kernels ran at a tenth of their speed (6-28 TF, profiles/r02_bench_launch_shapes.txt);
+    the frontend backward that follows is throughput-bound and shares the chip gracefully.  Triggers, whichever comes
+    first: ops.flush_deferred() - called from the hook on the encoder INPUT's gradient (encoder.py) and by
+    dp.GradientExchange before it all-reduces the decoder segment (N > 1: the exchange must see finished gradients, so
+    there the flush stays where it was) - or the end-of-backward engine callback (frozen encoder)."""
+
+    def __init__(self, wg, rows_of, R, main, side):
+        self.args = (wg, rows_of, R, main, side)
+        self.device_index = main.device_index
+
+    def arm(self):
+        ops._armed.setdefault(self.device_index, []).append(self)
+        torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        if self.args is None:
+            return
+        args, self.args = self.args, None
+        lst = ops._armed.get(self.device_index, [])
+        if self in lst:
+            lst.remove(self)
+        _flush_weight_grads(*args)
 
 
 def _flush_weight_grads(wg, rows_of, R, main, side):

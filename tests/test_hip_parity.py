@@ -688,7 +688,8 @@ def _seg_attention_bwd(ops, do, q, k, v, p, B, H, segL, Lk_fixed, drop_p, seed, 
 
 @pytest.mark.parametrize("segL,Lk_fixed,causal", [((3, 16, 9), 0, True), ((1, 2), 0, False), ((5, 16, 7, 1), 29, False),
                                                   ((16,), 32, False), ((4,), 13, False), ((12, 20), 29, False),
-                                                  ((1, 2, 3, 4, 5, 6, 7, 8, 9, 10), 29, False)])
+                                                  ((1, 2, 3, 4, 5, 6, 7, 8, 9, 10), 29, False),
+                                                  (tuple(range(1, 17)), 29, False), ((16, 3, 1, 9, 2, 2, 7, 5, 11), 32, False)])
 def test_segmented_attention_decoder_sizes(ops, segL, Lk_fixed, causal):
     """The ragged attention entry points at decoder sizes (<= 16 queries, <= 32 keys take the one-wavefront-per-problem
     kernels; the (12, 20) case the workgroup kernel) against fp64 torch, forward and backward, plus the dropout path
@@ -1072,21 +1073,40 @@ def test_stage_batched_decoder_dropout_masks_match_between_forward_and_backward(
     ops.join_side_streams()
     torch.cuda.synchronize()
     grad = flat.flat_grad.clone()
-    a, b = flat.ranges["decoder."]
+    names = {id(p): n for n, p in m.named_parameters()}
     gen = torch.Generator(DEV).manual_seed(5)
-    for trial in range(3):
-        v = torch.zeros_like(flat.flat_param)
-        v[a:b] = torch.randn(b - a, device=DEV, generator=gen)
-        ana = float((grad.double() * v.double()).sum())
-        eps = 2e-4
+
+    def probe(v, eps):
         base = flat.flat_param.clone()
         vals = []
         for sgn in (1.0, -1.0):
             flat.flat_param.copy_(base + sgn * eps * v)
             vals.append(float(loss_fn().detach().double()))      # grad mode stays on: same (stage-batched) code path
         flat.flat_param.copy_(base)
-        num = (vals[0] - vals[1]) / (2 * eps)
-        assert abs(num - ana) < 1.5e-2 * abs(ana) + 2e-2, (trial, num, ana)    # measured 0.3 %; a wrong mask gives O(1)
+        return (vals[0] - vals[1]) / (2 * eps), float((grad.double() * v.double()).sum())
+
+    # Directions along the gradient of parameter groups whose own curvature is small (measured on this model with
+    # tools/scratch-style sweeps: central differences of the embedding / LayerNorm / Q,K-projection groups agree with the
+    # analytic value to 1e-4 .. 1.6e-3 at eps = 1e-4, while the V / fc / FFN matrices show 2-15 % of pure eps^2 truncation
+    # error, with and without dropout alike).  The embedding is upstream of every dropout site of both directions and every
+    # sub-layer's LayerNorm / projection gradient crosses the sites above it, so a mismatching mask anywhere moves these
+    # derivatives by far more than the 1 % bound.
+    for pats in (("tgt_word_emb",), ("layer_norm",), ("attn.w_qs", "attn.w_ks")):
+        v = torch.zeros_like(flat.flat_param)
+        for p, off, _ in flat.slots:
+            nm = names[id(p)]
+            if nm.startswith("decoder") and any(q in nm for q in pats):
+                g = grad[off:off + p.numel()]
+                v[off:off + p.numel()] = g / g.norm().clamp_min(1e-20) * (p.numel() ** 0.5)
+        num, ana = probe(v, 5e-5)       # (truncation error ~ eps^2: 1.05 % was seen for the Q,K group at 1e-4)
+        assert abs(ana) > 10.0 and abs(num - ana) < 1e-2 * abs(ana), (pats, num, ana)
+    # ... and one random direction over every decoder parameter as a coarse check (kinks of 17 M ReLU units and the
+    # curvature above leave up to ~7 % / 0.35 absolute between the two at this step size; a wrong mask gives O(1))
+    a, b = flat.ranges["decoder."]
+    v = torch.zeros_like(flat.flat_param)
+    v[a:b] = torch.randn(b - a, device=DEV, generator=gen)
+    num, ana = probe(v, 1e-4)
+    assert abs(num - ana) < 0.1 * abs(ana) + 0.5, (num, ana)
 
 
 @pytest.mark.parametrize("B", [3, 16])
