@@ -18,7 +18,10 @@
  *   - activations of the visual trunk are NHWC ("channels last"): (image, h, w, c), image =
  *     n*T + t — the reference's transpose/contiguous/view (SBL/transformer/video_frontend.py:113-115)
  *     is folded into the layout.  Transformer tensors are row-major (B, L, 512).
- *   - fp32 everywhere (the reference's dtype); matrix products use v_mfma_f32_32x32x2_f32.
+ *   - tensors are fp32 in memory everywhere (the reference's dtype).  The arithmetic of the matrix products of the
+ *     tile engine is a process-wide setting, sbl_set_matmul_precision() below: exact fp32 MFMA
+ *     (v_mfma_f32_32x32x2_f32, the library default) or split-bf16 MFMA with fp32 accumulation.  The setting is read
+ *     when a launch is ENQUEUED: a captured hipGraph keeps the mode it was captured under, whatever is set later.
  */
 #ifndef SBL_HIP_H
 #define SBL_HIP_H
@@ -55,7 +58,9 @@ int sbl_profile_last_kernel(void);
  *      per product) at 6 x 32 instead of 8 x 64 MFMA cycles per 32x32x16 block;
  *   3  two planes, three products (~2^-17 per product);   1  plain bf16 inputs with fp32 accumulation — BASELINE
  *      config 5 "mixed bf16" (fp32 master weights, fp32 accumulate).
- * Inputs and outputs stay fp32 in memory in every mode.  Returns SBL_ERR_INVALID for any other value. */
+ * Inputs and outputs stay fp32 in memory in every mode.  Returns SBL_ERR_INVALID for any other value.
+ * The value is read at enqueue time and baked into captured hipGraphs (re-capture after changing it).  Mode 6's
+ * "exact split" holds for |x| >= 2^-110 or x == 0; residual planes of smaller magnitudes underflow bf16's range. */
 int sbl_set_matmul_precision(int terms);
 int sbl_get_matmul_precision(void);
 
@@ -266,6 +271,19 @@ int sbl_attention_seg_bwd(const float* dout, long lddo, const float* q, long ldq
                           long ldv, const float* p, float* dq, long lddq, float* dk, long lddk, float* dv, long lddv,
                           int B, int H, const int* seg_L, int nseg, int Lk_fixed, float scale, float drop_p,
                           const uint64_t* seed, uint64_t offset, sbl_stream_t stream);
+/* Stage head of the SBL decoder for BOTH directions in one launch: out_d = dropout(emb[tok_d] + pe[:L]) for every segment
+ * of the stage (SBL/transformer/decoder.py:116-120); mask = f(seed, offset_d, element index inside the stage's rows), the
+ * indexing of sbl_dropout, which regenerates it in backward.  drop_p == 0: plain embedding + PE. */
+int sbl_embed_pe_drop2_fwd(const int64_t* tok0, const int64_t* tok1, long ldt, const float* emb, const float* pe, float* out0,
+                           float* out1, int B, const int* seg_L, int nseg, int D, int V, float drop_p, const uint64_t* seed,
+                           uint64_t offset0, uint64_t offset1, sbl_stream_t stream);
+/* Stage tail of the SBL decoder in one launch (SBL/transformer/decoder.py:160-186): the last cross-direction fusion at the
+ * last position of every sequence (A'[L-1] = A[L-1] + B[0], B'[L-1] = 2 B[L-1] + A[0]) -> last_d (nseg*B, 512), the two
+ * bias-free Linear(512, V) heads -> pred_d (nseg*B, ldp), and - write_tok != 0 - ys_d[b, step + 1] = argmax of the stage's
+ * final segment (first maximal index).  yf_d: the last layer's outputs of the stage's rows; D must be 512, V <= 64. */
+int sbl_decoder_tail_fwd(const float* yf0, const float* yf1, const float* w0, const float* w1, float* last0, float* last1,
+                         float* pred0, float* pred1, long ldp, int64_t* ys0, int64_t* ys1, long ldy, int step, int write_tok,
+                         int B, const int* seg_L, int nseg, int D, int V, sbl_stream_t stream);
 int sbl_embed_pe_seg_fwd(const int64_t* tok, long ldt, const float* emb, const float* pe, float* out, int B,
                          const int* seg_L, int nseg, int D, int V, sbl_stream_t stream);
 int sbl_embed_seg_bwd(const int64_t* tok, long ldt, const float* dy, float* demb, int B, const int* seg_L, int nseg, int D,

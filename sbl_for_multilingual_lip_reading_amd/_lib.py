@@ -49,6 +49,8 @@ SIGNATURES = {
     "sbl_add_layernorm2_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, F, P, U64, U64, P],
     "sbl_attention_seg_bwd": [P, L, P, L, P, L, P, L, P, P, L, P, L, P, L, I, I, P, I, I, F, F, P, U64, P],
     "sbl_embed_pe_seg_fwd": [P, L, P, P, P, I, P, I, I, I, P],
+    "sbl_embed_pe_drop2_fwd": [P, P, L, P, P, P, P, I, P, I, I, I, F, P, U64, U64, P],
+    "sbl_decoder_tail_fwd": [P, P, P, P, P, P, P, P, L, P, P, L, I, I, I, P, I, I, I, P],
     "sbl_embed_seg_bwd": [P, L, P, P, I, P, I, I, I, P],
     "sbl_fusion_seg_fwd": [P, P, P, P, I, P, I, I, P],
     "sbl_fusion_seg_bwd": [P, P, P, P, I, P, I, I, P],

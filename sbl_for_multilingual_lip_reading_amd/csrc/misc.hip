@@ -216,6 +216,136 @@ extern "C" int sbl_argmax_select(const float* pred, long ldp, const int64_t* gol
     return 0;
 }
 
+// ------------------------------------------------------------------ stage head: embedding + PE + dropout, both directions
+// decoder.py:116-120 for the l2r and r2l token buffers of one stage in ONE launch (blockIdx.y = direction): what
+// sbl_embed_pe_seg_fwd + sbl_dropout did in four.  The mask is a function of (seed, offset_d, element index inside this
+// stage's rows), exactly the indexing of dropout_kernel, so the backward regenerates it with sbl_dropout as before.
+__global__ __launch_bounds__(256) void embed_pe_drop2_kernel(const int64_t* __restrict__ tok0, const int64_t* __restrict__ tok1, long ldt,
+                                                             const float* __restrict__ emb, const float* __restrict__ pe,
+                                                             float* __restrict__ out0, float* __restrict__ out1, int B, SegDesc segs,
+                                                             long rows, int D4, int V, uint32_t thresh, float keep_scale,
+                                                             const uint64_t* __restrict__ seed, uint64_t offset0, uint64_t offset1) {
+    const int64_t* tok = blockIdx.y ? tok1 : tok0;
+    float* out = blockIdx.y ? out1 : out0;
+    const uint64_t offset = blockIdx.y ? offset1 : offset0;
+    const uint64_t sd = thresh ? *seed : 0;
+    const long n4 = rows * D4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const int r = (int)(i / D4);
+        const int s = sbl_seg_of_row(segs, r, B);
+        const int L = segs.L[s], rr = r - segs.row_off[s];
+        const int b = rr / L, l = rr - b * L;
+        long t = tok[(long)b * ldt + l];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+        const float4 e = reinterpret_cast<const float4*>(emb)[t * D4 + c];
+        const float4 p = reinterpret_cast<const float4*>(pe)[(long)l * D4 + c];
+        float4 v = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+        if (thresh) {
+            const uint64_t i0 = (uint64_t)i * 4;
+            v.x = sbl_keep(sd, offset, i0 + 0, thresh) ? v.x * keep_scale : 0.f;
+            v.y = sbl_keep(sd, offset, i0 + 1, thresh) ? v.y * keep_scale : 0.f;
+            v.z = sbl_keep(sd, offset, i0 + 2, thresh) ? v.z * keep_scale : 0.f;
+            v.w = sbl_keep(sd, offset, i0 + 3, thresh) ? v.w * keep_scale : 0.f;
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+extern "C" int sbl_embed_pe_drop2_fwd(const int64_t* tok0, const int64_t* tok1, long ldt, const float* emb, const float* pe,
+                                      float* out0, float* out1, int B, const int* seg_L, int nseg, int D, int V, float drop_p,
+                                      const uint64_t* seed, uint64_t offset0, uint64_t offset1, sbl_stream_t stream) {
+    SegDesc d;
+    const long rows = sbl_make_segs(d, seg_L, nseg, B, 1, 1);
+    SBL_REQUIRE(rows > 0, "sbl_embed_pe_drop2_fwd: bad segment list");
+    SBL_REQUIRE(tok0 && tok1 && emb && pe && out0 && out1 && B > 0 && D > 0 && D % 4 == 0 && V > 0, "sbl_embed_pe_drop2_fwd: bad args");
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_embed_pe_drop2_fwd: bad dropout args");
+    for (int s = 0; s < nseg; ++s) SBL_REQUIRE(ldt >= seg_L[s], "sbl_embed_pe_drop2_fwd: token row shorter than prefix %d", seg_L[s]);
+    SBL_REQUIRE(sbl_aligned16(emb) && sbl_aligned16(pe) && sbl_aligned16(out0) && sbl_aligned16(out1), "sbl_embed_pe_drop2_fwd: unaligned");
+    hipLaunchKernelGGL(embed_pe_drop2_kernel, dim3(ew_grid(rows * D / 4), 2), dim3(256), 0, (hipStream_t)stream, tok0, tok1, ldt, emb, pe,
+                       out0, out1, B, d, rows, D / 4, V, drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset0,
+                       offset1);
+    SBL_LAUNCH_CHECK("sbl_embed_pe_drop2_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ stage tail: last fusion + heads + token feedback
+// After the last decoder layer of a stage the reference fuses the two directions (decoder.py:160-164), takes the LAST
+// position of every sequence (:166-167), applies the two bias-free Linear(512, 58) heads and feeds the arg-max back
+// (:173-186).  Only the last positions are ever read from that fusion: A'[L-1] = A[L-1] + B[0], B'[L-1] = 2 B[L-1] + A[0]
+// (time flip along the sequence's own prefix).  One wavefront per (direction, segment, batch row) forms that 512-vector
+// (kept as `last`: the heads' weight gradient reads it), its 58 logits (fp32 FMA, wave-shuffle sums) and, for the
+// stage's final step when the coin says "own arg-max", the next token (first maximal index, torch.argmax's CPU rule).
+// One launch instead of fusion + 2 x (gather_last + GEMM + argmax_select).
+__global__ __launch_bounds__(256) void decoder_tail_kernel(const float* __restrict__ yf0, const float* __restrict__ yf1,
+                                                           const float* __restrict__ w0, const float* __restrict__ w1,
+                                                           float* __restrict__ last0, float* __restrict__ last1,
+                                                           float* __restrict__ pred0, float* __restrict__ pred1, long ldp,
+                                                           int64_t* __restrict__ ys0, int64_t* __restrict__ ys1, long ldy, int step,
+                                                           int write_tok, int B, SegDesc segs, int V) {
+    const int lane = threadIdx.x & 63;
+    const int sb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sb >= segs.nseg * B) return;      // whole wavefront; no barrier in this kernel
+    const int dir = blockIdx.y;
+    const int s = sb / B, b = sb - s * B;
+    const int L = segs.L[s];
+    const long r0 = segs.row_off[s] + (long)b * L, rl = r0 + L - 1;
+    const float* own = (dir ? yf1 : yf0) + rl * 512;      // this direction's last position
+    const float* oth = (dir ? yf0 : yf1) + r0 * 512;      // the other direction's first (= time-flipped last) position
+    const float k = dir ? 2.f : 1.f;
+    float x[8];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(own + lane * 4), a1 = *reinterpret_cast<const float4*>(own + 256 + lane * 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(oth + lane * 4), c1 = *reinterpret_cast<const float4*>(oth + 256 + lane * 4);
+        x[0] = k * a0.x + c0.x; x[1] = k * a0.y + c0.y; x[2] = k * a0.z + c0.z; x[3] = k * a0.w + c0.w;
+        x[4] = k * a1.x + c1.x; x[5] = k * a1.y + c1.y; x[6] = k * a1.z + c1.z; x[7] = k * a1.w + c1.w;
+    }
+    float* lo = (dir ? last1 : last0) + (long)sb * 512;
+    *reinterpret_cast<float4*>(lo + lane * 4) = make_float4(x[0], x[1], x[2], x[3]);
+    *reinterpret_cast<float4*>(lo + 256 + lane * 4) = make_float4(x[4], x[5], x[6], x[7]);
+    const float* w = dir ? w1 : w0;
+    float mine = -INFINITY;      // lane c keeps logit c
+    for (int c = 0; c < V; ++c) {
+        const float4 u0 = *reinterpret_cast<const float4*>(w + (long)c * 512 + lane * 4);
+        const float4 u1 = *reinterpret_cast<const float4*>(w + (long)c * 512 + 256 + lane * 4);
+        float acc = x[0] * u0.x;
+        acc = fmaf(x[1], u0.y, acc); acc = fmaf(x[2], u0.z, acc); acc = fmaf(x[3], u0.w, acc);
+        acc = fmaf(x[4], u1.x, acc); acc = fmaf(x[5], u1.y, acc); acc = fmaf(x[6], u1.z, acc); acc = fmaf(x[7], u1.w, acc);
+        acc = wave_sum(acc);
+        if (lane == (c & 63)) mine = acc;
+    }
+    float* po = (dir ? pred1 : pred0) + (long)sb * ldp;
+    if (lane < V) po[lane] = mine;
+    if (write_tok && s == segs.nseg - 1) {
+        float best = lane < V ? mine : -INFINITY;
+        int bi = lane < V ? lane : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) (dir ? ys1 : ys0)[(long)b * ldy + step + 1] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+extern "C" int sbl_decoder_tail_fwd(const float* yf0, const float* yf1, const float* w0, const float* w1, float* last0, float* last1,
+                                    float* pred0, float* pred1, long ldp, int64_t* ys0, int64_t* ys1, long ldy, int step,
+                                    int write_tok, int B, const int* seg_L, int nseg, int D, int V, sbl_stream_t stream) {
+    SegDesc d;
+    SBL_REQUIRE(sbl_make_segs(d, seg_L, nseg, B, 1, 1) > 0, "sbl_decoder_tail_fwd: bad segment list");
+    SBL_REQUIRE(D == 512 && V >= 1 && V <= 64 && ldp >= V && B > 0, "sbl_decoder_tail_fwd: built for d_model = 512 and at most 64 classes (D=%d V=%d)", D, V);
+    SBL_REQUIRE(yf0 && yf1 && w0 && w1 && last0 && last1 && pred0 && pred1, "sbl_decoder_tail_fwd: null operand");
+    SBL_REQUIRE(!write_tok || (ys0 && ys1 && step >= 0 && step + 1 < ldy), "sbl_decoder_tail_fwd: token feedback needs ys buffers and step + 1 < ldy");
+    SBL_REQUIRE(sbl_aligned16(yf0) && sbl_aligned16(yf1) && sbl_aligned16(w0) && sbl_aligned16(w1) && sbl_aligned16(last0) && sbl_aligned16(last1),
+                "sbl_decoder_tail_fwd: unaligned");
+    hipLaunchKernelGGL(decoder_tail_kernel, dim3(sbl_cdiv((long)nseg * B, 4), 2), dim3(256), 0, (hipStream_t)stream, yf0, yf1, w0, w1, last0,
+                       last1, pred0, pred1, ldp, ys0, ys1, ldy, step, write_tok, B, d, V);
+    SBL_LAUNCH_CHECK("sbl_decoder_tail_fwd");
+    return 0;
+}
+
 // ------------------------------------------------------------------ Decoder.preprocess, decoder.py:62-77
 // One thread per target row: strip IGNORE_ID keeping the order, <sos> in front of the input form, <eos> padding to maxlen in
 // both forms.  set = 0 / 1: the l2r / r2l targets of one step in one launch (torch's argsort + gather + where + fills were

@@ -1029,6 +1029,67 @@ class SmoothedCEFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- #
 # visual frontend
 # --------------------------------------------------------------------------- #
+# Packed convolution weights.  The state dict keeps OIHW; the kernels read OHWI (forward / weight gradient) and
+# [Cin][kh][kw][Cout] (input gradient).  Weights change once per optimizer step, not once per forward, so the two packed
+# images of each of the 19 trunk convolutions are kept and re-made only when the weight changed:
+#   * torch in-place updates (torch.optim, load_state_dict, copy_) bump `w._version` - or the flat buffer's version when the
+#     parameter is a view of a dp.FlatModel - and the next forward re-packs;
+#   * writers that bypass torch (FusedAdam's raw kernel on the flat buffer) call refresh_packed_weights(), which re-packs
+#     every cached image IN PLACE right away, so hipGraphs captured with the cached images stay valid across optimizer steps.
+# A captured graph that is replayed between FOREIGN in-place updates must call refresh_packed_weights() itself.
+PACK_CACHE = True
+_packed = {}          # id(weight) -> entry
+_pack_epoch = [0]
+
+
+def _pack_key(w):
+    fm = getattr(w, "_sbl_flat", None)
+    return (w.data_ptr(), w._version, fm.flat_param._version if fm is not None else -1, _pack_epoch[0])
+
+
+def _pack_entry_alive(e):
+    return e["ref"]() is not None
+
+
+def packed_conv_weight(w, need_dg, stats):
+    """(w_ohwi, w_dg) for an OIHW convolution weight; `stats` (fp64, 2*Cout, or None) is zero-filled for the caller either
+    by the pack launch (as before) or, on a cache hit, here."""
+    import weakref
+    Cout, Cin, KH, KW = w.shape
+    dev = w.device
+    e = _packed.get(id(w)) if PACK_CACHE else None
+    if e is not None and (e["ref"]() is not w or e["shape"] != tuple(w.shape)):
+        e = None
+    if e is not None and e["key"] == _pack_key(w) and (e["dg"] is not None or not need_dg):
+        if stats is not None:
+            stats.zero_()
+        return e["ohwi"], e["dg"]
+    w_ohwi = e["ohwi"] if e is not None else torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
+    w_dg = e["dg"] if (e is not None and e["dg"] is not None) else (torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if need_dg else None)
+    call("sbl_conv_weight_pack", _p(w.detach().contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _p(stats),
+         stats.numel() if stats is not None else 0, _s())
+    if PACK_CACHE:
+        _packed[id(w)] = {"ref": weakref.ref(w), "shape": tuple(w.shape), "key": _pack_key(w), "ohwi": w_ohwi, "dg": w_dg}
+        if len(_packed) > 256:
+            for k in [k for k, v in _packed.items() if not _pack_entry_alive(v)]:
+                del _packed[k]
+    return w_ohwi, w_dg
+
+
+def refresh_packed_weights():
+    """Re-pack every cached image in place from the current weights (current stream).  FusedAdam.step calls it; callers
+    that update parameters by other raw kernels, or replay captured graphs between foreign in-place updates, must too."""
+    _pack_epoch[0] += 1
+    for k, e in list(_packed.items()):
+        w = e["ref"]()
+        if w is None or not w.is_cuda:
+            del _packed[k]
+            continue
+        Cout, Cin, KH, KW = w.shape
+        call("sbl_conv_weight_pack", _p(w.detach().contiguous()), _p(e["ohwi"]), _p(e["dg"]), Cout, Cin, KH, KW, None, 0, _s())
+        e["key"] = _pack_key(w)
+
+
 class StemFn(torch.autograd.Function):
     """frontend3D (video_frontend.py:99-104) on (N,T,H,W) clips -> pooled NHWC (N*T, H/4, W/4, 64)."""
 
@@ -1100,14 +1161,19 @@ class ConvBNFn(torch.autograd.Function):
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
         dev = x.device
-        w_ohwi = torch.empty(Cout, KH, KW, Cin, device=dev, dtype=torch.float32)
-        # the input-gradient layout [Cin][kh][kw][Cout] is packed by the same launch and kept for backward
-        w_dg = torch.empty(Cin, KH, KW, Cout, device=dev, dtype=torch.float32) if (training and ctx.needs_input_grad[0]) else None
-        # (the pack launch also zeroes the BN statistics the convolution's epilogue accumulates into.  Measured and not kept:
-        # all 19 packs on the side stream while the stem runs - same-box A/B 32.94 vs 32.72 ms, the fork/join and the
-        # contention with the stem cost more than the 10 us per convolution they take off the chain)
-        stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64) if training else None
-        call("sbl_conv_weight_pack", _p(w.contiguous()), _p(w_ohwi), _p(w_dg), Cout, Cin, KH, KW, _p(stats), 2 * Cout if training else 0, _s())
+        # packed weight images (OHWI; and [Cin][kh][kw][Cout] for the input gradient, kept for backward): cached across
+        # steps, see packed_conv_weight.  The BN statistics the convolution's epilogue accumulates into come zero-filled from
+        # the step's pooled memset (or are zeroed by the pack launch / a fill when the pool is not armed).
+        # (Measured and not kept in round 2: all 19 packs on the side stream while the stem runs - same-box A/B 32.94 vs
+        # 32.72 ms, the fork/join and the contention with the stem cost more than the 10 us per convolution they take off.)
+        stats = None
+        pooled_stats = False
+        if training:
+            stats = zero_pool_take(dev, (2 * Cout,), torch.float64)
+            pooled_stats = stats is not None
+            if not pooled_stats:
+                stats = torch.empty(2 * Cout, device=dev, dtype=torch.float64)
+        w_ohwi, w_dg = packed_conv_weight(w, training and ctx.needs_input_grad[0], None if pooled_stats else stats)
         conv = torch.empty(NIMG, Ho, Wo, Cout, device=dev, dtype=torch.float32)
         mean = torch.empty(Cout, device=dev, dtype=torch.float32)
         invstd = torch.empty(Cout, device=dev, dtype=torch.float32)

@@ -115,8 +115,9 @@ class DecoderStagesFn(torch.autograd.Function):
                                 q=E(R, HD), att2=E(R, HD), pe=E(pe_off[ML]), o_e=E(R, D), mu_e=E(R), rs_e=E(R), y_e=E(R, D),
                                 h=E(R, F_), o_f=E(R, D), mu_f=E(R), rs_f=E(R), y_f=E(R, D), kv=None,
                                 off=[st.next_offset() for _ in range(5)] if training else [0] * 5)
-        xout = [E(R, D), E(R, D)]
-        x0 = [E(R, D) if p_emb > 0 else None for _ in (0, 1)]        # pre-dropout embeddings are not needed afterwards
+        lazy_io = not (getattr(dec, "fuse_stage_io", True) and D == 512 and V <= 64)
+        xout = [E(R, D), E(R, D)] if lazy_io else [None, None]      # (the fused stage tail never materialises the last fusion)
+        x0 = [E(R, D) if (p_emb > 0 and lazy_io) else None for _ in (0, 1)]        # pre-dropout embeddings are not needed afterwards
         off_emb = [st.next_offset() if p_emb > 0 else 0 for _ in (0, 1)]
         last = [E(ML * N, D), E(ML * N, D)]
         pred = [E(ML * N, V), E(ML * N, V)]
@@ -247,16 +248,24 @@ class DecoderStagesFn(torch.autograd.Function):
             ops.gemm2(M, D, F_, sl(b0, "h"), sl(b1, "h"), F_, L0.w2, L1.w2, F_, sl(b0, "o_f"), sl(b1, "o_f"), D, L0.b2, L1.b2)
             ln2("o_f", "y_e", "y_f", "mu_f", "rs_f", L0.ln_f, L1.ln_f, L0.drop_f, 4)
 
+        fused_io = getattr(dec, "fuse_stage_io", True) and D == 512 and V <= 64
         for (i0, i1) in stages:
             segL = tuple(range(i0 + 1, i1 + 2))
             seg_arr, nseg = segs(segL)
             r0, r1 = rowoff[i0], rowoff[i1 + 1]
             M = r1 - r0
-            for d in (0, 1):
-                dst = x0[d][r0:r1] if p_emb > 0 else B_[d][0]["x"][r0:r1]
-                call("sbl_embed_pe_seg_fwd", _p(ys[d]), ys[d].stride(0), _p(emb), _p(pe_tab), _p(dst), N, seg_arr, nseg, D, V, ops._s())
-                if p_emb > 0:
-                    call("sbl_dropout", _p(dst), _p(B_[d][0]["x"][r0:r1]), M * D, p_emb, _p(seed), _fold(off_emb[d], r0 * D), ops._s())
+            if fused_io:
+                # stage head: embedding + PE + dropout of both directions in one launch (the pre-dropout embeddings are not
+                # needed afterwards: backward regenerates the mask)
+                call("sbl_embed_pe_drop2_fwd", _p(ys[0]), _p(ys[1]), ys[0].stride(0), _p(emb), _p(pe_tab), _p(B_[0][0]["x"][r0:r1]),
+                     _p(B_[1][0]["x"][r0:r1]), N, seg_arr, nseg, D, V, p_emb, _p(seed) if p_emb > 0 else None,
+                     _fold(off_emb[0], r0 * D), _fold(off_emb[1], r0 * D), ops._s())
+            else:
+                for d in (0, 1):
+                    dst = x0[d][r0:r1] if p_emb > 0 else B_[d][0]["x"][r0:r1]
+                    call("sbl_embed_pe_seg_fwd", _p(ys[d]), ys[d].stride(0), _p(emb), _p(pe_tab), _p(dst), N, seg_arr, nseg, D, V, ops._s())
+                    if p_emb > 0:
+                        call("sbl_dropout", _p(dst), _p(B_[d][0]["x"][r0:r1]), M * D, p_emb, _p(seed), _fold(off_emb[d], r0 * D), ops._s())
             for n in range(nl):
                 if merged:
                     layer_fwd2(n, r0, r1, i0, segL)
@@ -268,11 +277,19 @@ class DecoderStagesFn(torch.autograd.Function):
                             layer_fwd(d, n, r0, r1, i0, segL)
                     if side is not None:
                         main.wait_stream(side)
+                if n + 1 == nl and fused_io:
+                    break          # the last fusion is only ever read at the last positions: it lives in the stage tail below
                 nxt = [B_[d][n + 1]["x"][r0:r1] if n + 1 < nl else xout[d][r0:r1] for d in (0, 1)]
                 call("sbl_fusion_seg_fwd", _p(B_[0][n]["y_f"][r0:r1]), _p(B_[1][n]["y_f"][r0:r1]), _p(nxt[0]), _p(nxt[1]), N, seg_arr, nseg,
                      D, ops._s())
+            lrows = slice(i0 * N, (i1 + 1) * N)
+            if fused_io:
+                # stage tail: last fusion at the last positions + both heads + the token fed to the next stage, one launch
+                call("sbl_decoder_tail_fwd", _p(B_[0][nl - 1]["y_f"][r0:r1]), _p(B_[1][nl - 1]["y_f"][r0:r1]), _p(heads[0]), _p(heads[1]),
+                     _p(last[0][lrows]), _p(last[1][lrows]), _p(pred[0][lrows]), _p(pred[1][lrows]), V, _p(ys[0]), _p(ys[1]),
+                     ys[0].stride(0), i1, int(bool(coins[i1])), N, seg_arr, nseg, D, V, ops._s())
+                continue
             for d in (0, 1):
-                lrows = slice(i0 * N, (i1 + 1) * N)
                 call("sbl_gather_last_fwd", _p(xout[d][r0:r1]), _p(last[d][lrows]), N, seg_arr, nseg, D, ops._s())
                 gemm(0, 1, nseg * N, V, D, last[d][lrows], D, heads[d], D, pred[d][lrows], V)
             if coins[i1]:

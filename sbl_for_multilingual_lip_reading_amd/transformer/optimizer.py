@@ -59,6 +59,8 @@ class FusedAdam(object):
         for a, b in self.flat.trainable_ranges():
             self._ops.adam_step(self.flat.flat_param[a:b], self.flat.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
                                 g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count, self.grad_scale)
+        # the kernel wrote the weights behind torch's back: re-pack the cached convolution weight images in place
+        self._ops.refresh_packed_weights()
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

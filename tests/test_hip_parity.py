@@ -1479,6 +1479,55 @@ def test_encoder_return_attns(ops):
         assert maxdiff(a.sum(-1), torch.ones(24, 29)) < 1e-5
 
 
+def test_fused_stage_head_and_tail_kernels(ops):
+    """sbl_embed_pe_drop2_fwd and sbl_decoder_tail_fwd (one launch each for both directions) against the launches they
+    replace: embedding + PE (+ dropout with the same mask) and fusion -> gather_last -> Linear(512, 58) -> argmax_select
+    (decoder.py:116-120,160-186), on a ragged stage with B not a multiple of 4."""
+    import ctypes
+    B, D, V, segL = 5, 512, 58, (3, 4, 5, 6)
+    R = B * sum(segL)
+    arr = (ctypes.c_int * len(segL))(*segL)
+    ns = len(segL)
+    emb, pe = U("hd.emb", (V, D)).to(DEV), U("hd.pe", (32, D)).to(DEV)
+    toks = [torch.from_numpy(((detfill.uniform("hd.tok%d" % d, (B, 17)) + 1) * 29).astype(np.int64).clip(0, 57)).to(DEV) for d in (0, 1)]
+    seed = torch.tensor([12345], dtype=torch.int64, device=DEV)
+    for p_drop in (0.0, 0.25):
+        outs = [torch.empty(R, D, device=DEV) for _ in (0, 1)]
+        ops.call("sbl_embed_pe_drop2_fwd", toks[0].data_ptr(), toks[1].data_ptr(), 17, emb.data_ptr(), pe.data_ptr(), outs[0].data_ptr(),
+                 outs[1].data_ptr(), B, arr, ns, D, V, p_drop, seed.data_ptr() if p_drop else None, 40, 41, ops._s())
+        for d in (0, 1):
+            ref = torch.empty(R, D, device=DEV)
+            ops.call("sbl_embed_pe_seg_fwd", toks[d].data_ptr(), 17, emb.data_ptr(), pe.data_ptr(), ref.data_ptr(), B, arr, ns, D, V, ops._s())
+            if p_drop:
+                ref2 = torch.empty_like(ref)
+                ops.call("sbl_dropout", ref.data_ptr(), ref2.data_ptr(), R * D, p_drop, seed.data_ptr(), 40 + d, ops._s())
+                ref = ref2
+            assert torch.equal(outs[d], ref), (p_drop, d)
+    ya, yb = U("tl.a", (R, D)).to(DEV), U("tl.b", (R, D)).to(DEV)
+    w = [U("tl.w%d" % d, (V, D), 0.1).to(DEV) for d in (0, 1)]
+    last = [torch.empty(ns * B, D, device=DEV) for _ in (0, 1)]
+    pred = [torch.empty(ns * B, V, device=DEV) for _ in (0, 1)]
+    ys = [torch.full((B, 17), -7, dtype=torch.long, device=DEV) for _ in (0, 1)]
+    step = 5
+    ops.call("sbl_decoder_tail_fwd", ya.data_ptr(), yb.data_ptr(), w[0].data_ptr(), w[1].data_ptr(), last[0].data_ptr(), last[1].data_ptr(),
+             pred[0].data_ptr(), pred[1].data_ptr(), V, ys[0].data_ptr(), ys[1].data_ptr(), 17, step, 1, B, arr, ns, D, V, ops._s())
+    a2, b2 = torch.empty_like(ya), torch.empty_like(yb)
+    ops.call("sbl_fusion_seg_fwd", ya.data_ptr(), yb.data_ptr(), a2.data_ptr(), b2.data_ptr(), B, arr, ns, D, ops._s())
+    for d, x in ((0, a2), (1, b2)):
+        rl = torch.empty(ns * B, D, device=DEV)
+        ops.call("sbl_gather_last_fwd", x.data_ptr(), rl.data_ptr(), B, arr, ns, D, ops._s())
+        assert torch.equal(last[d], rl), d
+        refp = rl.double().cpu() @ w[d].double().cpu().t()
+        assert maxdiff(pred[d], refp) < 2e-5
+        tok = pred[d][(ns - 1) * B:].argmax(-1)
+        assert torch.equal(ys[d][:, step + 1], tok) and bool((ys[d][:, :step + 1] == -7).all()) and bool((ys[d][:, step + 2:] == -7).all())
+    # write_tok = 0 leaves the token buffers alone
+    ys2 = [y.clone() for y in ys]
+    ops.call("sbl_decoder_tail_fwd", ya.data_ptr(), yb.data_ptr(), w[0].data_ptr(), w[1].data_ptr(), last[0].data_ptr(), last[1].data_ptr(),
+             pred[0].data_ptr(), pred[1].data_ptr(), V, ys2[0].data_ptr(), ys2[1].data_ptr(), 17, step + 1, 0, B, arr, ns, D, V, ops._s())
+    assert torch.equal(ys2[0], ys[0]) and torch.equal(ys2[1], ys[1])
+
+
 # --------------------------------------------------------------------------- size-independent properties at BASELINE sizes
 def test_full_size_properties(ops):
     """B=32, T=29, 88x88 (BASELINE config 2/3 sizes): properties that need no CPU reference."""
