@@ -272,63 +272,106 @@ extern "C" int sbl_embed_pe_drop2_fwd(const int64_t* tok0, const int64_t* tok1, 
 // After the last decoder layer of a stage the reference fuses the two directions (decoder.py:160-164), takes the LAST
 // position of every sequence (:166-167), applies the two bias-free Linear(512, 58) heads and feeds the arg-max back
 // (:173-186).  Only the last positions are ever read from that fusion: A'[L-1] = A[L-1] + B[0], B'[L-1] = 2 B[L-1] + A[0]
-// (time flip along the sequence's own prefix).  One wavefront per (direction, segment, batch row) forms that 512-vector
+// (time flip along the sequence's own prefix).  The kernel forms that 512-vector per (direction, segment, batch row)
 // (kept as `last`: the heads' weight gradient reads it), its 58 logits (fp32 FMA, wave-shuffle sums) and, for the
 // stage's final step when the coin says "own arg-max", the next token (first maximal index, torch.argmax's CPU rule).
 // One launch instead of fusion + 2 x (gather_last + GEMM + argmax_select).
+// Workgroup = 4 rows x 64 class slots: wavefront w owns classes 16w .. 16w+15 for all four rows (a weight row is loaded once
+// and used four times; all 32 of a wavefront's 16-byte weight loads are independent and issued up front), each lane forms
+// 64 partial sums (row, class) over its 8 of the 512 columns, and a transposing butterfly (32+16+8+4+2+1 shuffles) leaves
+// lane (r, cl) with the full dot product of row r and class 16w + cl.  (A first version looped over the 58 classes with one
+// 6-shuffle wave sum each: 35 us per launch, the L2 round trip of every class exposed.)
 __global__ __launch_bounds__(256) void decoder_tail_kernel(const float* __restrict__ yf0, const float* __restrict__ yf1,
                                                            const float* __restrict__ w0, const float* __restrict__ w1,
                                                            float* __restrict__ last0, float* __restrict__ last1,
                                                            float* __restrict__ pred0, float* __restrict__ pred1, long ldp,
                                                            int64_t* __restrict__ ys0, int64_t* __restrict__ ys1, long ldy, int step,
                                                            int write_tok, int B, SegDesc segs, int V) {
-    const int lane = threadIdx.x & 63;
-    const int sb = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (sb >= segs.nseg * B) return;      // whole wavefront; no barrier in this kernel
+    __shared__ float s_logit[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dir = blockIdx.y;
-    const int s = sb / B, b = sb - s * B;
-    const int L = segs.L[s];
-    const long r0 = segs.row_off[s] + (long)b * L, rl = r0 + L - 1;
-    const float* own = (dir ? yf1 : yf0) + rl * 512;      // this direction's last position
-    const float* oth = (dir ? yf0 : yf1) + r0 * 512;      // the other direction's first (= time-flipped last) position
-    const float k = dir ? 2.f : 1.f;
-    float x[8];
-    {
+    const int nrows = segs.nseg * B;
+    const float kf = dir ? 2.f : 1.f;
+    const float* ya = dir ? yf1 : yf0;      // this direction
+    const float* yb = dir ? yf0 : yf1;      // the other one
+    float x[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int sb = min((int)blockIdx.x * 4 + r, nrows - 1);      // clamped: rows past the end are computed, never stored
+        const int s = sb / B, b = sb - s * B;
+        const int L = segs.L[s];
+        const long r0 = segs.row_off[s] + (long)b * L, rl = r0 + L - 1;
+        const float* own = ya + rl * 512;      // last position
+        const float* oth = yb + r0 * 512;      // the other direction's first (= time-flipped last) position
         const float4 a0 = *reinterpret_cast<const float4*>(own + lane * 4), a1 = *reinterpret_cast<const float4*>(own + 256 + lane * 4);
         const float4 c0 = *reinterpret_cast<const float4*>(oth + lane * 4), c1 = *reinterpret_cast<const float4*>(oth + 256 + lane * 4);
-        x[0] = k * a0.x + c0.x; x[1] = k * a0.y + c0.y; x[2] = k * a0.z + c0.z; x[3] = k * a0.w + c0.w;
-        x[4] = k * a1.x + c1.x; x[5] = k * a1.y + c1.y; x[6] = k * a1.z + c1.z; x[7] = k * a1.w + c1.w;
+        x[r][0] = kf * a0.x + c0.x; x[r][1] = kf * a0.y + c0.y; x[r][2] = kf * a0.z + c0.z; x[r][3] = kf * a0.w + c0.w;
+        x[r][4] = kf * a1.x + c1.x; x[r][5] = kf * a1.y + c1.y; x[r][6] = kf * a1.z + c1.z; x[r][7] = kf * a1.w + c1.w;
     }
-    float* lo = (dir ? last1 : last0) + (long)sb * 512;
-    *reinterpret_cast<float4*>(lo + lane * 4) = make_float4(x[0], x[1], x[2], x[3]);
-    *reinterpret_cast<float4*>(lo + 256 + lane * 4) = make_float4(x[4], x[5], x[6], x[7]);
-    const float* w = dir ? w1 : w0;
-    float mine = -INFINITY;      // lane c keeps logit c
-    for (int c = 0; c < V; ++c) {
-        const float4 u0 = *reinterpret_cast<const float4*>(w + (long)c * 512 + lane * 4);
-        const float4 u1 = *reinterpret_cast<const float4*>(w + (long)c * 512 + 256 + lane * 4);
-        float acc = x[0] * u0.x;
-        acc = fmaf(x[1], u0.y, acc); acc = fmaf(x[2], u0.z, acc); acc = fmaf(x[3], u0.w, acc);
-        acc = fmaf(x[4], u1.x, acc); acc = fmaf(x[5], u1.y, acc); acc = fmaf(x[6], u1.z, acc); acc = fmaf(x[7], u1.w, acc);
-        acc = wave_sum(acc);
-        if (lane == (c & 63)) mine = acc;
-    }
-    float* po = (dir ? pred1 : pred0) + (long)sb * ldp;
-    if (lane < V) po[lane] = mine;
-    if (write_tok && s == segs.nseg - 1) {
-        float best = lane < V ? mine : -INFINITY;
-        int bi = lane < V ? lane : 0x7fffffff;
+    {   // wavefront w stores row w of `last`
+        const int sb = (int)blockIdx.x * 4 + wave;
+        if (sb < nrows) {
+            float* lo = (dir ? last1 : last0) + (long)sb * 512;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) {
-                best = ov;
-                bi = oi;
-            }
+            for (int r = 0; r < 4; ++r)
+                if (r == wave) {
+                    *reinterpret_cast<float4*>(lo + lane * 4) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
+                    *reinterpret_cast<float4*>(lo + 256 + lane * 4) = make_float4(x[r][4], x[r][5], x[r][6], x[r][7]);
+                }
         }
-        if (lane == 0) (dir ? ys1 : ys0)[(long)b * ldy + step + 1] = bi == 0x7fffffff ? 0 : bi;
     }
+    const float* w = dir ? w1 : w0;
+    float v[64];      // v[r * 16 + cl]: partial dot product of row r and class 16 * wave + cl over this lane's 8 columns
+    float4 u0[16], u1[16];
+#pragma unroll
+    for (int cl = 0; cl < 16; ++cl) {
+        const int c = min(wave * 16 + cl, V - 1);
+        u0[cl] = *reinterpret_cast<const float4*>(w + (long)c * 512 + lane * 4);
+        u1[cl] = *reinterpret_cast<const float4*>(w + (long)c * 512 + 256 + lane * 4);
+    }
+#pragma unroll
+    for (int cl = 0; cl < 16; ++cl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = x[r][0] * u0[cl].x;
+            acc = fmaf(x[r][1], u0[cl].y, acc); acc = fmaf(x[r][2], u0[cl].z, acc); acc = fmaf(x[r][3], u0[cl].w, acc);
+            acc = fmaf(x[r][4], u1[cl].x, acc); acc = fmaf(x[r][5], u1[cl].y, acc); acc = fmaf(x[r][6], u1[cl].z, acc);
+            acc = fmaf(x[r][7], u1[cl].w, acc);
+            v[r * 16 + cl] = acc;
+        }
+    // transposing butterfly: after the step with offset o, a lane keeps the half of its values whose index has bit o equal to
+    // its own lane bit o; lane l ends with the sum over all lanes of v[l]
+#define SBL_TSTEP(N, O)                                                       \
+    _Pragma("unroll") for (int j = 0; j < (N) / 2; ++j) {                     \
+        const bool hi = (lane & (O)) != 0;                                    \
+        const float keep = hi ? v[j + (N) / 2] : v[j];                        \
+        const float send = hi ? v[j] : v[j + (N) / 2];                        \
+        v[j] = keep + __shfl_xor(send, (O), 64);                              \
+    }
+    SBL_TSTEP(64, 32) SBL_TSTEP(32, 16) SBL_TSTEP(16, 8) SBL_TSTEP(8, 4) SBL_TSTEP(4, 2) SBL_TSTEP(2, 1)
+#undef SBL_TSTEP
+    {
+        const int r = lane >> 4, c = wave * 16 + (lane & 15);
+        const int sb = (int)blockIdx.x * 4 + r;
+        s_logit[r][c] = c < V ? v[0] : -INFINITY;
+        if (sb < nrows && c < V) (dir ? pred1 : pred0)[(long)sb * ldp + c] = v[0];
+    }
+    if (!write_tok) return;      // (workgroup-uniform)
+    __syncthreads();
+    const int sb = (int)blockIdx.x * 4 + wave;
+    if (sb >= nrows || sb / B != segs.nseg - 1) return;      // token feedback: the stage's final step only
+    float best = s_logit[wave][lane];
+    int bi = lane < V ? lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) (dir ? ys1 : ys0)[(long)(sb - (segs.nseg - 1) * B) * ldy + step + 1] = bi == 0x7fffffff ? 0 : bi;
 }
 extern "C" int sbl_decoder_tail_fwd(const float* yf0, const float* yf1, const float* w0, const float* w1, float* last0, float* last1,
                                     float* pred0, float* pred1, long ldp, int64_t* ys0, int64_t* ys1, long ldy, int step,
