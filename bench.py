@@ -111,6 +111,7 @@ def parse():
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: set an attribute of the decoder module (e.g. fuse_stage_io=0, fuse_kv_projections=0) or, with an "
                          "'ops.' prefix, of the ops module, before the step is built")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KNOB=VALUE", help="A/B: sbl_set_tuning(knob, value) before the step is built")
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the secondary exact-fp32 measurement (`f32_exact` in the JSON line)")
     ap.add_argument("--per-step-decoder", action="store_true", help="one decoder stage per step (no run batching)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -331,6 +332,8 @@ def main():
     lib = _lib.load()          # fail loudly if the HIP library is missing
     ops.set_matmul_precision(args.precision)
     ops.PACK_CACHE = not args.no_pack_cache
+    for kv in args.tuning:
+        ops.call("sbl_set_tuning", *[int(v) for v in kv.split("=")])
     rec = LaunchRecorder()
 
     B = args.batch
@@ -645,7 +648,7 @@ def main():
                        "matmul_precision": args.precision,
                        "per_gpu_batch": B, "global_batch": B * world, "clip": "%dx%dx%d" % (args.T, args.HW, args.HW), "parallelism": "dp%d" % world,
                        "dropout": not args.no_dropout, "bn": "train", "issue": mode, "trial_ms": trial_ms or None, "hipgraph": graph is not None, "graphs_per_step": 2 if (graph is not None and use_split) else 1,
-                       "decoder_streams": 1 if args.single_stream else 2, "conv_weight_pack": "per step" if args.no_pack_cache else "cached (re-packed when weights change)", "ab_overrides": args.set or None,
+                       "decoder_streams": 1 if args.single_stream else 2, "conv_weight_pack": "per step" if args.no_pack_cache else "cached (re-packed when weights change)", "ab_overrides": (args.set + ["tuning " + t for t in args.tuning]) or None,
                        "decoder_schedule": "per-step" if args.per_step_decoder else "teacher-forced runs batched",
                        "coin_patterns": len(patterns), "own_argmax_coins": [sum(p_) for p_ in patterns],
                        "mean_own_argmax_coins": round(sum(timed_coins) / max(len(timed_coins), 1), 3),      # over the timed steps; expectation 8

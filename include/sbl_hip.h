@@ -63,6 +63,11 @@ int sbl_profile_last_kernel(void);
  * "exact split" holds for |x| >= 2^-110 or x == 0; residual planes of smaller magnitudes underflow bf16's range. */
 int sbl_set_matmul_precision(int terms);
 int sbl_get_matmul_precision(void);
+/* Measurement knobs (process-wide, read at enqueue time like the precision; results are the same either way).
+ * knob 0: wave-group K split of the dense 64x64 split-bf16 tiles (512-thread workgroups), 1 = on (default), 0 = off;
+ * knob 1: number of 64x64 output tiles from which a dense product takes 128x128 tiles (default 4096);
+ * knob 2: largest tile count of a launch that takes the wave-group K split (default 320). */
+int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear
  * C[M,N] (+)= opA(A)[M,K] * opB(B)[K,N], row-major; opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k],
@@ -220,6 +225,13 @@ int sbl_seed_bump(uint64_t* seed, sbl_stream_t stream);
 int sbl_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                           float* mean, float* rstd, int M, int D, float eps, float drop_p, const uint64_t* seed,
                           uint64_t offset, sbl_stream_t stream);
+/* sbl_add_layernorm2_fwd followed by the SBL cross-direction fusion (SBL/transformer/module.py:50-51 then decoder.py:127-143)
+ * in one launch: xn0 = A + flip(B), xn1 = 2B + flip(A), A / B = the two directions' LayerNorm(dropout(x_d) + res_d) rows of a
+ * ragged stage (B sequences per segment of length seg_L[s]; flip along each sequence's own prefix).  A / B are not stored. */
+int sbl_add_layernorm2_fusion_fwd(const float* x0, const float* x1, const float* res0, const float* res1, const float* gamma0,
+                                  const float* gamma1, const float* beta0, const float* beta1, float* xn0, float* xn1, float* mean0,
+                                  float* mean1, float* rstd0, float* rstd1, int B, const int* seg_L, int nseg, int D, float eps,
+                                  float drop_p, const uint64_t* seed, uint64_t offset0, uint64_t offset1, sbl_stream_t stream);
 /* The same for two same-shape problems (the two decoder directions) in one launch. */
 int sbl_add_layernorm2_fwd(const float* x0, const float* x1, const float* res0, const float* res1, const float* gamma0,
                            const float* gamma1, const float* beta0, const float* beta1, float* y0, float* y1, float* mean0,

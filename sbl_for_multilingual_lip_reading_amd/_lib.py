@@ -47,6 +47,7 @@ SIGNATURES = {
     "sbl_attention_seg2_fwd": [P, P, L, P, P, L, P, P, L, P, P, L, P, P, I, I, I, P, I, I, F, F, P, U64, U64, P],
     "sbl_gemm2_f32": [I, I, I, P, P, L, P, P, L, P, P, L, P, P, I, P, L, P],
     "sbl_add_layernorm2_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, F, P, U64, U64, P],
+    "sbl_add_layernorm2_fusion_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, F, F, P, U64, U64, P],
     "sbl_attention_seg_bwd": [P, L, P, L, P, L, P, L, P, P, L, P, L, P, L, I, I, P, I, I, F, F, P, U64, P],
     "sbl_embed_pe_seg_fwd": [P, L, P, P, P, I, P, I, I, I, P],
     "sbl_embed_pe_drop2_fwd": [P, P, L, P, P, P, P, I, P, I, I, I, F, P, U64, U64, P],
@@ -67,6 +68,7 @@ SIGNATURES = {
     "sbl_adam_step": [P, P, P, P, L, F, F, F, F, I, F, P],
     "sbl_preprocess_clips": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "sbl_set_matmul_precision": [I],
+    "sbl_set_tuning": [I, I],
 }
 
 _lib = None

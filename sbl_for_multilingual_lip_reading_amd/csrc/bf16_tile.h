@@ -79,7 +79,12 @@ __device__ __forceinline__ bf16x8 bf_frag(const unsigned char* img, int rb, int 
 #ifndef SBL_ABL
 #define SBL_ABL 0
 #endif
-template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int NT>
+// NH = 2 (64x64 tiles, no split-K over workgroups): the workgroup has 512 threads = two groups of four wavefronts; group h
+// stages and multiplies the slabs 2j + h of the tile's K range in its own pair of LDS buffers, with its own accumulators, and
+// the two partial tiles meet once in LDS before the epilogue.  Same global traffic as one group, half the barrier intervals
+// per tile, twice the loads and MFMAs in flight per tile: these launches have only ~2 tiles per CU and every tile is a serial
+// chain of 32-128 slab iterations, so the chain length, not the chip, bounds them.
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int NT, int NH = 1>
 __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
                                                  int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
                                                  bool colsum_tile) {
@@ -93,8 +98,13 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
     constexpr int WM = 4 / WN;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int RD = KU != 1 ? 1 : (TM * TN == 1 ? 4 : 2);      // register ring depth (below)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(NH == 1 || (NH == 2 && RD == 4), "wave-group K split: 64x64 tiles only");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[NH * 2 * BUF];
+    const int half = NH == 2 ? (int)(threadIdx.x >> 8) : 0;
+    unsigned char* smem = smem_all + half * (2 * BUF);
+    constexpr int KS = NH * SBL_BK;              // K stride between consecutive slabs of one wave group
+    const int hoff = half * SBL_BK;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     sbl_stamp_begin(sc.stamp);
 
@@ -157,20 +167,20 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
         typename BL::Regs qb[RD];
 #pragma unroll
         for (int q = 0; q < RD; ++q) {
-            al.load(sa, kbeg + q * SBL_BK, kend, qa[q]);
-            bl.load(sb, kbeg + q * SBL_BK, kend, qb[q]);
+            al.load(sa, kbeg + hoff + q * KS, kend, qa[q]);
+            bl.load(sb, kbeg + hoff + q * KS, kend, qb[q]);
         }
         if (do_colsum) al.accum(qa[0], cs);
         bf_store<AL, BM, NPL>(smem, qa[0], tid);
         bf_store<BL, BN, NPL>(smem + A_BUF, qb[0], tid);
-        al.load(sa, kbeg + RD * SBL_BK, kend, qa[0]);
-        bl.load(sb, kbeg + RD * SBL_BK, kend, qb[0]);
+        al.load(sa, kbeg + hoff + RD * KS, kend, qa[0]);
+        bl.load(sb, kbeg + hoff + RD * KS, kend, qb[0]);
         __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += RD * SBL_BK) {
+        for (int k0 = kbeg; k0 < kend; k0 += RD * KS) {
 #pragma unroll
             for (int q = 0; q < RD; ++q) {
-                const int k = k0 + q * SBL_BK;          // slab in LDS buffer q & 1; ring slot (q + 1) % RD holds slab k + 16
-                if (k >= kend) break;
+                const int k = k0 + q * KS;              // (workgroup-uniform: the first slab of this barrier interval)
+                if (k >= kend) break;                   // slab k + hoff in LDS buffer q & 1; ring slot (q + 1) % RD holds the next
                 unsigned char* nb = smem + ((q + 1) & 1) * BUF;
                 if (do_colsum) al.accum(qa[(q + 1) % RD], cs);
                 if (!(SBL_ABL & 4)) {
@@ -181,12 +191,33 @@ __device__ __forceinline__ void sbl_gemm_tile_bf(const AL& al, const BL& bl, con
                     asm volatile("" ::"v"(ka.x), "v"(ka.y), "v"(ka.z), "v"(ka.w), "v"(kb.x), "v"(kb.y), "v"(kb.z), "v"(kb.w));
                 }
                 if (!(SBL_ABL & 8)) {
-                    al.load(sa, k + (RD + 1) * SBL_BK, kend, qa[(q + 1) % RD]);
-                    bl.load(sb, k + (RD + 1) * SBL_BK, kend, qb[(q + 1) % RD]);
+                    al.load(sa, k + hoff + (RD + 1) * KS, kend, qa[(q + 1) % RD]);
+                    bl.load(sb, k + hoff + (RD + 1) * KS, kend, qb[(q + 1) % RD]);
                 }
                 compute(smem + (q & 1) * BUF);
                 __syncthreads();
             }
+        }
+        if constexpr (NH == 2) {
+            // (every wavefront is past its last LDS operand read: the loop ends on a barrier)
+            float* red = reinterpret_cast<float*>(smem_all);
+            if (half == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[r * 256 + tid] = acc[0][0][r];
+            }
+            __syncthreads();
+            if (half == 1) {
+                if (do_colsum) {      // this group's share of the bias-gradient column sums
+                    const int c = al.col(sa);
+                    if (c + 0 < M) atomicAdd(sc.a_colsum + c + 0, cs.x);
+                    if (c + 1 < M) atomicAdd(sc.a_colsum + c + 1, cs.y);
+                    if (c + 2 < M) atomicAdd(sc.a_colsum + c + 2, cs.z);
+                    if (c + 3 < M) atomicAdd(sc.a_colsum + c + 3, cs.w);
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r * 256 + tid];
         }
     } else if constexpr (RD == 2) {
         typename AL::Regs qa[RD];

@@ -54,6 +54,16 @@ extern "C" int sbl_set_matmul_precision(int terms) {
     return 0;
 }
 extern "C" int sbl_get_matmul_precision(void) { return g_sbl_prec; }
+int g_sbl_wave_ksplit = 1;
+int g_sbl_ksplit_tiles = 320;      // knob 2 (same-box A/B of the whole step: 0 -> 32.99, 320 -> 32.81, 768 -> 32.99 ms)
+int g_sbl_big_min = 4096;          // knob 1
+extern "C" int sbl_set_tuning(int knob, int value) {
+    SBL_REQUIRE(knob >= 0 && knob <= 2 && value >= 0, "sbl_set_tuning: unknown knob %d / value %d (0 = wave-group K split on/off, 1 = 64x64-tile count from which dense products take 128x128 tiles, 2 = largest tile count that takes the wave-group K split)", knob, value);
+    if (knob == 0) g_sbl_wave_ksplit = value != 0;
+    else if (knob == 1) g_sbl_big_min = value;
+    else g_sbl_ksplit_tiles = value;
+    return 0;
+}
 
 // ------------------------------------------------------------------ dispatch
 template <class AL, class BL, int BM, int BN, int KU>
@@ -117,7 +127,7 @@ extern "C" int sbl_gemm_f32(int transA, int transB, int M, int N, int K, const f
                 "sbl_gemm_f32: operand spans more than 2 GiB (buffer descriptor range)");
     const bool plain = !bias && !relu && !relu_mask;
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    constexpr int big_min = 4096;   // tuning knob (4352x2048x512: 128x128 tiles 131 us, 64x64 115 us)
+    const int big_min = g_sbl_big_min;   // tuning knob (4352x2048x512: 128x128 tiles 131 us, 64x64 115 us)
     const bool big = (M >= 1024 && N >= 256 && tiles64 >= big_min);
     // split K when the output has too few 64x64 tiles to fill 256 CUs: aim at ~256 workgroups, chunks of at
     // least one 64-deep macro step, at most 8 slices (the last-arriving workgroup reads every slab)
@@ -205,7 +215,7 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     const bool vec = sbl_aligned16(A0) && sbl_aligned16(A1) && sbl_aligned16(B0) && sbl_aligned16(B1) && lda % 4 == 0 && ldb % 4 == 0 && K % 8 == 0;
     SBL_REQUIRE(sbl_fits_u32((long)M * lda) && sbl_fits_u32((long)N * ldb), "sbl_gemm2_f32: operand spans more than 2 GiB (buffer descriptor range)");
     const long tiles64 = (long)sbl_cdiv(M, 64) * sbl_cdiv(N, 64);
-    constexpr int big_min = 4096;
+    const int big_min = g_sbl_big_min;
     const bool big = (M >= 1024 && N >= 256 && 2 * tiles64 >= big_min);
     if (!vec || big) {      // shapes the decoder forward does not produce: two plain launches
         if (int e = sbl_gemm_f32(0, 1, M, N, K, A0, lda, B0, ldb, C0, ldc, bias0, relu, nullptr, 0, 0, nullptr, ws, ws_bytes, stream)) return e;

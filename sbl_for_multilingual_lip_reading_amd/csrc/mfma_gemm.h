@@ -329,20 +329,24 @@ __device__ __forceinline__ void sbl_gemm_tile_f32(const AL& al, const BL& bl, co
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); PREC = 1 / 3 / 6: bf16 MFMA on 1 / 2 / 3 bf16 planes per operand
 // (bf16_tile.h: 6 = every product of an exact 3-way split whose weight is >= 2^-16, i.e. fp32-grade results).
-template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int PREC = 0>
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN, int PREC = 0, int NH = 1>
 __device__ __forceinline__ void sbl_gemm_tile(const AL& al, const BL& bl, const EPI& epi, const SplitCtl& sc, int M, int N,
                                               int m0, int n0, int kbeg, int kend, int tile, int z, int nz,
                                               bool colsum_tile) {
+    static_assert(PREC != 0 || NH == 1, "the fp32 body has no wave-group K split");
     if constexpr (PREC == 0)
         sbl_gemm_tile_f32<AL, BL, EPI, BM, BN, KU, WN>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
     else      // the bf16 bodies always stage one 16-deep slab per barrier: at 6 / 3 / 1 MFMAs per 32x32x16 block they are bound by
               // operand conversion and load latency, which more resident workgroups (less LDS each) hide better than longer
               // macro steps (4352x512x512 alone: 29 us at KU = 1 against 37 us at KU = 2)
-        sbl_gemm_tile_bf<AL, BL, EPI, BM, BN, 1, WN, PREC>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
+        sbl_gemm_tile_bf<AL, BL, EPI, BM, BN, 1, WN, PREC, NH>(al, bl, epi, sc, M, N, m0, n0, kbeg, kend, tile, z, nz, colsum_tile);
 }
 
 // Matrix-product precision of the tile engine (sbl_set_matmul_precision): 0 = fp32 MFMA, 6 / 3 / 1 = bf16 MFMA terms.
 extern int g_sbl_prec;
+extern int g_sbl_wave_ksplit;      // A/B knobs (sbl_set_tuning): wave-group K split on / off,
+extern int g_sbl_ksplit_tiles;     // ... the largest tile count that takes it,
+extern int g_sbl_big_min;          // ... and the 64x64-tile count from which dense products take 128x128 tiles
 #define SBL_PREC_LAUNCH(KERNEL_P, grid, s, ...)                                                         \
     do {                                                                                                \
         switch (g_sbl_prec) {                                                                           \
@@ -353,13 +357,41 @@ extern int g_sbl_prec;
         }                                                                                               \
     } while (0)
 
+// Same for kernels with a wave-group K split (last template argument NH): the split-bf16 bodies of 64x64 tiles launch 512
+// threads (NH = 2) when the launch has no split-K over workgroups; the fp32 body always runs NH = 1.
+#define SBL_PREC_LAUNCH_NH(KERNEL_PN, nh, grid, s, ...)                                                        \
+    do {                                                                                                       \
+        if ((nh) == 2 && g_sbl_prec != 0) {                                                                    \
+            switch (g_sbl_prec) {                                                                              \
+                case 6: hipLaunchKernelGGL((KERNEL_PN(6, 2)), grid, dim3(512), 0, s, __VA_ARGS__); break;      \
+                case 3: hipLaunchKernelGGL((KERNEL_PN(3, 2)), grid, dim3(512), 0, s, __VA_ARGS__); break;      \
+                default: hipLaunchKernelGGL((KERNEL_PN(1, 2)), grid, dim3(512), 0, s, __VA_ARGS__); break;     \
+            }                                                                                                  \
+        } else {                                                                                               \
+            switch (g_sbl_prec) {                                                                              \
+                case 6: hipLaunchKernelGGL((KERNEL_PN(6, 1)), grid, dim3(256), 0, s, __VA_ARGS__); break;      \
+                case 3: hipLaunchKernelGGL((KERNEL_PN(3, 1)), grid, dim3(256), 0, s, __VA_ARGS__); break;      \
+                case 1: hipLaunchKernelGGL((KERNEL_PN(1, 1)), grid, dim3(256), 0, s, __VA_ARGS__); break;      \
+                default: hipLaunchKernelGGL((KERNEL_PN(0, 1)), grid, dim3(256), 0, s, __VA_ARGS__); break;     \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+
+// When the wave-group K split pays (measured inside the step, same shapes with and without it): launches of about one tile
+// per CU, where a tile's serial slab chain bounds the launch - 2 x 960 x 512 x 2048 58 -> 39 us, 2 x 960 x 512 x 512
+// 18 -> 15 us.  At two tiles per CU single launches still gain (4352 x 512 x 1536 110 -> 91 us) but the step does not (the
+// two decoder directions' launches share the chip, and 48 KB / 512-thread workgroups co-reside worse); with 8.5 tiles per CU
+// (4352 x 2048 x 512) the large workgroups halve the resident tiles: 129 -> 206 us.  Whole-step A/B on one box: threshold
+// 0 / 320 / 768 tiles -> 32.99 / 32.81 / 32.99 ms.  Never with split-K over workgroups (the slab reduction has barriers).
+static inline bool sbl_wave_ksplit_pays(long tiles, int nz) { return nz == 1 && g_sbl_wave_ksplit && tiles <= g_sbl_ksplit_tiles; }
+
 // XCD-aware tile order (x_off < 0 selects it; the real offset is then -x_off - 1).  Workgroups go to the 8 XCDs
 // round-robin by linear id, each XCD with its own L2.  With the plain (x fastest) order the n-tiles that share one
 // A row block land on different XCDs and every L2 fetches that block again.  Here XCD c works through a contiguous
 // range of the n-fastest tile order, so an A row block is fetched by one L2 and only the (small) B operand by all 8.
-template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2, int PREC = 0>
-__global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
-                                                            int kchunk, int x_off) {
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int WN = 2, int PREC = 0, int NH = 1>
+__global__ __launch_bounds__(256 * NH) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI epi, SplitCtl sc, int M, int N, int K,
+                                                                 int kchunk, int x_off) {
     int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
     if (x_off < 0) {
         // over the whole 3-D grid: the K-slices z of a weight-gradient launch share nothing, but the n-tiles of one
@@ -375,8 +407,8 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm_kernel(AL al, BL bl, EPI ep
         x_off = -x_off - 1;
     }
     const int kbeg = z * kchunk;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN, PREC>(al, bl, epi, sc, M, N, (x + x_off) * BM, y * BN, kbeg,
-                                                     min(K, kbeg + kchunk), y * gridDim.x + x, z, gridDim.z, y == 0);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, WN, PREC, NH>(al, bl, epi, sc, M, N, (x + x_off) * BM, y * BN, kbeg,
+                                                         min(K, kbeg + kchunk), y * gridDim.x + x, z, gridDim.z, y == 0);
 }
 
 // Two problems of one shape in one launch (the two decoder directions; see SkinnyDual): blockIdx.y in [Y, 2Y) works on
@@ -387,9 +419,9 @@ struct GemmDual {
     float* C1;
     const float* bias1;
 };
-template <class AL, class BL, class EPI, int BM, int BN, int KU, int PREC = 0>
-__global__ __launch_bounds__(256) void sbl_mfma_gemm2_kernel(AL al, BL bl, EPI epi, SplitCtl sc, GemmDual du, int M, int N, int K,
-                                                             int kchunk) {
+template <class AL, class BL, class EPI, int BM, int BN, int KU, int PREC = 0, int NH = 1>
+__global__ __launch_bounds__(256 * NH) void sbl_mfma_gemm2_kernel(AL al, BL bl, EPI epi, SplitCtl sc, GemmDual du, int M, int N, int K,
+                                                                  int kchunk) {
     int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
     {   // XCD-aware order as in sbl_mfma_gemm_kernel, over both problems
         const int X = gridDim.x, Y2 = gridDim.y, XY = X * Y2, T = XY * gridDim.z;
@@ -411,8 +443,8 @@ __global__ __launch_bounds__(256) void sbl_mfma_gemm2_kernel(AL al, BL bl, EPI e
         epi.bias = du.bias1;
     }
     const int kbeg = z * kchunk;
-    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, 2, PREC>(al, bl, epi, sc, M, N, x * BM, y * BN, kbeg, min(K, kbeg + kchunk), tile, z,
-                                                    gridDim.z, false);
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, KU, 2, PREC, NH>(al, bl, epi, sc, M, N, x * BM, y * BN, kbeg, min(K, kbeg + kchunk), tile, z,
+                                                        gridDim.z, false);
 }
 template <class AL, class BL, class EPI, int BM, int BN, int KU>
 static inline void sbl_launch_gemm2(const AL& al, const BL& bl, const EPI& epi, const GemmDual& du, int M, int N, int K, int splits,
@@ -421,9 +453,15 @@ static inline void sbl_launch_gemm2(const AL& al, const BL& bl, const EPI& epi, 
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), 2 * sbl_cdiv(N, BN), nz);
-#define SBL_K_(P) sbl_mfma_gemm2_kernel<AL, BL, EPI, BM, BN, KU, P>
-    SBL_PREC_LAUNCH(SBL_K_, grid, s, al, bl, epi, sc, du, M, N, K, kchunk);
+    if constexpr (BM == 64 && BN == 64) {
+#define SBL_K_(P, H) sbl_mfma_gemm2_kernel<AL, BL, EPI, BM, BN, KU, P, H>
+        SBL_PREC_LAUNCH_NH(SBL_K_, sbl_wave_ksplit_pays((long)grid.x * grid.y, nz) ? 2 : 1, grid, s, al, bl, epi, sc, du, M, N, K, kchunk);
 #undef SBL_K_
+    } else {
+#define SBL_K_(P) sbl_mfma_gemm2_kernel<AL, BL, EPI, BM, BN, KU, P>
+        SBL_PREC_LAUNCH(SBL_K_, grid, s, al, bl, epi, sc, du, M, N, K, kchunk);
+#undef SBL_K_
+    }
 }
 
 // Position-major convolution tiles (ConvGatherPM x DenseKCTapList): the workgroup's tap list = union of the in-bounds
@@ -493,9 +531,15 @@ static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, i
     int kchunk = sbl_cdiv(sbl_cdiv(K, splits), MK) * MK;
     int nz = sbl_cdiv(K, kchunk);
     dim3 grid(sbl_cdiv(M, BM), sbl_cdiv(N, BN), nz);
-#define SBL_K_(P) sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN, P>
-    SBL_PREC_LAUNCH(SBL_K_, grid, s, al, bl, epi, sc, M, N, K, kchunk, -1);
+    if constexpr (BM == 64 && BN == 64 && WN == 2 && AL::kDenseOperand && BL::kDenseOperand) {
+#define SBL_K_(P, H) sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN, P, H>
+        SBL_PREC_LAUNCH_NH(SBL_K_, sbl_wave_ksplit_pays((long)grid.x * grid.y, nz) ? 2 : 1, grid, s, al, bl, epi, sc, M, N, K, kchunk, -1);
 #undef SBL_K_
+    } else {
+#define SBL_K_(P) sbl_mfma_gemm_kernel<AL, BL, EPI, BM, BN, KU, WN, P>
+        SBL_PREC_LAUNCH(SBL_K_, grid, s, al, bl, epi, sc, M, N, K, kchunk, -1);
+#undef SBL_K_
+    }
 }
 
 // Tail splitting.  Every tile of these launches is resident at once, so a launch lasts as long as its fullest CU:

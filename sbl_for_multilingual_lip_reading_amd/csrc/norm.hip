@@ -437,6 +437,72 @@ __global__ __launch_bounds__(256) void add_layernorm2_fwd_kernel(LnFwdSet a0, Ln
     add_layernorm_fwd_rows(a.x, a.res, a.gamma, a.beta, a.y, a.mean, a.rstd, M, eps, thresh, keep_scale, seed, a.offset);
 }
 
+// ------------------------------------------------------------------ last LayerNorm of a decoder layer + SBL fusion
+// decoder.py:127-143: after the feed-forward sub-layer of layer n the two directions are fused, A' = A + flip(B), B' = 2B +
+// flip(A) (time flip along each sequence's own prefix), and A', B' are the next layer's inputs.  A'[l] and B'[L-1-l] need
+// exactly the same two LayerNorm rows - A[l] and B[L-1-l] - so one wavefront normalises those two rows (module.py:50-51,
+// dropout on the sub-layer output included) and writes both fused rows: the LayerNorm outputs themselves are never
+// stored (backward re-derives everything from the pre-norm sums, mean and rstd) and the separate fusion launch and its
+// pass over two (rows, 512) tensors per layer disappear.
+__device__ __forceinline__ void ln_row_regs(const LnFwdSet& a, int row, float eps, uint32_t thresh, float keep_scale, uint64_t sd,
+                                            int lane, float (&out)[8]) {
+    const long o = (long)row * 512;
+    float v[8];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(a.x + o + lane * 4);
+    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(a.x + o + 256 + lane * 4);
+    if (thresh) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t idx = (uint64_t)o + (k < 4 ? 0 : 256) + lane * 4 + (k & 3);
+            v[k] = sbl_keep(sd, a.offset, idx, thresh) ? v[k] * keep_scale : 0.f;
+        }
+    }
+    if (a.res) {
+        const float4 r0 = *reinterpret_cast<const float4*>(a.res + o + lane * 4);
+        const float4 r1 = *reinterpret_cast<const float4*>(a.res + o + 256 + lane * 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+    const float mu = wave_sum(s) * (1.f / 512.f);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q += (v[k] - mu) * (v[k] - mu);
+    const float rs = rsqrtf(wave_sum(q) * (1.f / 512.f) + eps);
+    const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + lane * 4), g1 = *reinterpret_cast<const float4*>(a.gamma + 256 + lane * 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(a.beta + lane * 4), b1 = *reinterpret_cast<const float4*>(a.beta + 256 + lane * 4);
+    out[0] = (v[0] - mu) * rs * g0.x + b0.x; out[1] = (v[1] - mu) * rs * g0.y + b0.y;
+    out[2] = (v[2] - mu) * rs * g0.z + b0.z; out[3] = (v[3] - mu) * rs * g0.w + b0.w;
+    out[4] = (v[4] - mu) * rs * g1.x + b1.x; out[5] = (v[5] - mu) * rs * g1.y + b1.y;
+    out[6] = (v[6] - mu) * rs * g1.z + b1.z; out[7] = (v[7] - mu) * rs * g1.w + b1.w;
+    if (lane == 0) {
+        a.mean[row] = mu;
+        a.rstd[row] = rs;
+    }
+}
+__global__ __launch_bounds__(256) void add_layernorm2_fusion_fwd_kernel(LnFwdSet a0, LnFwdSet a1, int B, SegDesc segs, int M, float eps,
+                                                                        uint32_t thresh, float keep_scale,
+                                                                        const uint64_t* __restrict__ seed) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;      // whole wavefront; no barrier in this kernel
+    const int s = sbl_seg_of_row(segs, r, B);
+    const int L = segs.L[s], l = (r - segs.row_off[s]) % L;
+    const int rm = r + (L - 1 - 2 * l);      // the time-flipped position of the same sequence
+    const uint64_t sd = thresh ? *seed : 0;
+    float a[8], b[8];
+    ln_row_regs(a0, r, eps, thresh, keep_scale, sd, lane, a);       // A[l]       (l2r direction)
+    ln_row_regs(a1, rm, eps, thresh, keep_scale, sd, lane, b);      // B[L-1-l]   (r2l direction)
+    float* xa = a0.y + (long)r * 512;       // A'[l]     = A[l] + B[L-1-l]
+    float* xb = a1.y + (long)rm * 512;      // B'[L-1-l] = 2 B[L-1-l] + A[l]
+    *reinterpret_cast<float4*>(xa + lane * 4) = make_float4(a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]);
+    *reinterpret_cast<float4*>(xa + 256 + lane * 4) = make_float4(a[4] + b[4], a[5] + b[5], a[6] + b[6], a[7] + b[7]);
+    *reinterpret_cast<float4*>(xb + lane * 4) = make_float4(2.f * b[0] + a[0], 2.f * b[1] + a[1], 2.f * b[2] + a[2], 2.f * b[3] + a[3]);
+    *reinterpret_cast<float4*>(xb + 256 + lane * 4) = make_float4(2.f * b[4] + a[4], 2.f * b[5] + a[5], 2.f * b[6] + a[6], 2.f * b[7] + a[7]);
+}
+
 // dz = rstd*(gamma*dy - mean(gamma*dy) - xhat*mean(gamma*dy*xhat)); dgamma += dy*xhat, dbeta += dy (column sums:
 // each wave walks its rows keeping 8 per-lane partials, LDS-combined per block, then float atomics)
 #define SBL_LN_BWD_WAVES 8       // 512-thread workgroups: 8 waves x RW rows in flight per workgroup
@@ -560,6 +626,32 @@ extern "C" int sbl_add_layernorm2_fwd(const float* x0, const float* x1, const fl
     hipLaunchKernelGGL(add_layernorm2_fwd_kernel, dim3(sbl_cdiv(M, 4), 2), dim3(256), 0, (hipStream_t)stream, a0, a1, M, eps,
                        drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed);
     SBL_LAUNCH_CHECK("sbl_add_layernorm2_fwd");
+    return 0;
+}
+
+/* LayerNorm(dropout(x_d) + res_d) of both decoder directions followed by the SBL cross-direction fusion, in one launch:
+ * xn0 = A + flip(B), xn1 = 2B + flip(A) with A / B the two LayerNorm outputs (never stored); mean / rstd as in
+ * sbl_add_layernorm2_fwd.  Rows are a ragged stage (B sequences per segment of length seg_L[s]). */
+extern "C" int sbl_add_layernorm2_fusion_fwd(const float* x0, const float* x1, const float* res0, const float* res1, const float* gamma0,
+                                             const float* gamma1, const float* beta0, const float* beta1, float* xn0, float* xn1,
+                                             float* mean0, float* mean1, float* rstd0, float* rstd1, int B, const int* seg_L, int nseg,
+                                             int D, float eps, float drop_p, const uint64_t* seed, uint64_t offset0, uint64_t offset1,
+                                             sbl_stream_t stream) {
+    SegDesc d;
+    const long rows = sbl_make_segs(d, seg_L, nseg, B, 1, 1);
+    SBL_REQUIRE(rows > 0 && rows < (1L << 30), "sbl_add_layernorm2_fusion_fwd: bad segment list");
+    SBL_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sbl_add_layernorm2_fusion_fwd: bad dropout args");
+    SBL_REQUIRE(D == 512, "sbl_add_layernorm2_fusion_fwd: D=%d (this build is specialised for d_model=512)", D);
+    SBL_REQUIRE(x0 && x1 && gamma0 && gamma1 && beta0 && beta1 && xn0 && xn1 && mean0 && mean1 && rstd0 && rstd1 && (!res0 == !res1),
+                "sbl_add_layernorm2_fusion_fwd: bad args");
+    SBL_REQUIRE(xn0 != x0 && xn0 != x1 && xn1 != x0 && xn1 != x1 && xn0 != res0 && xn0 != res1 && xn1 != res0 && xn1 != res1 && xn0 != xn1,
+                "sbl_add_layernorm2_fusion_fwd: outputs must not alias inputs (time flip)");
+    SBL_REQUIRE(sbl_aligned16(x0) && sbl_aligned16(x1) && sbl_aligned16(xn0) && sbl_aligned16(xn1) && (!res0 || (sbl_aligned16(res0) && sbl_aligned16(res1))) &&
+                    sbl_aligned16(gamma0) && sbl_aligned16(gamma1) && sbl_aligned16(beta0) && sbl_aligned16(beta1), "sbl_add_layernorm2_fusion_fwd: unaligned");
+    LnFwdSet a0{x0, res0, gamma0, beta0, xn0, mean0, rstd0, offset0}, a1{x1, res1, gamma1, beta1, xn1, mean1, rstd1, offset1};
+    hipLaunchKernelGGL(add_layernorm2_fusion_fwd_kernel, dim3(sbl_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a0, a1, B, d, (int)rows, eps,
+                       drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed);
+    SBL_LAUNCH_CHECK("sbl_add_layernorm2_fusion_fwd");
     return 0;
 }
 

@@ -67,6 +67,7 @@ template <int BR, bool VEC>
 struct DenseKC {
     static constexpr bool kColSum = false;
     static constexpr bool kKC = true;
+    static constexpr bool kDenseOperand = true;      // plain nn.Linear operand (the dense launches may split K over wave groups)
     const float* p;
     long ld;
     int rows;
@@ -115,6 +116,7 @@ template <int BR>
 struct DenseKCTaps {
     static constexpr bool kColSum = false;
     static constexpr bool kKC = true;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     long ld;
     int rows;
@@ -159,6 +161,7 @@ template <int BR>
 struct DenseKCTapList {
     static constexpr bool kColSum = false;
     static constexpr bool kKC = true;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     long ld;
     int rows;
@@ -200,6 +203,7 @@ template <int BR, bool VEC>
 struct DenseMC {
     static constexpr bool kColSum = true;
     static constexpr bool kKC = false;
+    static constexpr bool kDenseOperand = true;
     const float* p;
     long ld;
     int rows;
@@ -251,6 +255,7 @@ template <int BR, bool ALIGNED = false>
 struct SegMC {
     static constexpr bool kColSum = true;
     static constexpr bool kKC = false;
+    static constexpr bool kDenseOperand = false;
     const float* p[SBL_MAX_KSEG];
     int kcum[SBL_MAX_KSEG + 1];
     int nseg;
@@ -388,6 +393,7 @@ template <int BR, bool DGRAD>
 struct ConvGatherKC {
     static constexpr bool kColSum = false;
     static constexpr bool kKC = true;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     ConvGeom g;
     int rows;   // NIMG*OH*OW
@@ -435,6 +441,7 @@ template <int BR>
 struct ConvGatherMC {
     static constexpr bool kColSum = false;
     static constexpr bool kKC = false;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     ConvGeom g;
     int rows;   // KH*KW*C
@@ -488,6 +495,7 @@ template <int BR, bool DGRAD>
 struct ConvGatherPM {
     static constexpr bool kColSum = false;
     static constexpr bool kKC = true;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     ConvGeom g;
     int rows;   // NIMG*OH*OW
@@ -540,6 +548,7 @@ template <int BR>
 struct DenseMCPM {            // dY^T: element (co, k') = dy[pixel(k')][co]
     static constexpr bool kColSum = false;
     static constexpr bool kKC = false;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     long ld;
     int rows;
@@ -579,6 +588,7 @@ template <int BR>
 struct ConvGatherMCPM {       // x gathered: element ((tap, ci), k') = x[img, oh + dh, ow + dw, ci]
     static constexpr bool kColSum = false;
     static constexpr bool kKC = false;
+    static constexpr bool kDenseOperand = false;
     const float* p;
     ConvGeom g;
     int rows;   // KH*KW*C

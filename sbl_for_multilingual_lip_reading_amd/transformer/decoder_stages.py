@@ -124,9 +124,11 @@ class DecoderStagesFn(torch.autograd.Function):
         heads = (dec.tgt_word_prj_l2r.weight, dec.tgt_word_prj_r2l.weight)
         emb, pe_tab = dec.tgt_word_emb.weight, dec.positional_encoding.pe[0]
         golds = (gold_l2r, gold_r2l)
-        ys = [torch.full((N, ML + 1), dec.eos_id, dtype=torch.long, device=dev) for _ in (0, 1)]
-        for y in ys:
-            y[:, 0] = dec.sos_id
+        # token buffers: <sos> followed by the teacher tokens of every step (decoder.py:176-186 feeds gold[:, i] when coin i says
+        # so); the slots of the own-arg-max steps are overwritten by the stage tail before any later step reads them.  One
+        # concatenation per direction instead of a fill, a column store and one select launch per teacher-forced step.
+        sos_col = torch.full((N, 1), dec.sos_id, dtype=torch.long, device=dev)
+        ys = [torch.cat([sos_col, golds_[:, :ML].to(torch.long)], 1).contiguous() for golds_ in (gold_l2r, gold_r2l)]
         seed = st.seed
 
         # ---- hoisted cross-attention K/V (attention.py:42-43 for every layer and direction; step-invariant).  With the flat
@@ -172,10 +174,6 @@ class DecoderStagesFn(torch.autograd.Function):
                 j += 1
             stages.append((i, j))
             i = j + 1
-        for k in range(ML):
-            if not coins[k]:
-                for d in (0, 1):
-                    ops.argmax_select(None, golds[d], ys[d], k, 0)
 
         def layer_fwd(d, n, r0, r1, i0, segL):
             L, b = layers[d][n], B_[d][n]
@@ -211,7 +209,7 @@ class DecoderStagesFn(torch.autograd.Function):
             call("sbl_add_layernorm_fwd", _p(b["o_f"][r0:r1]), _p(y_e), _p(g), _p(be), _p(b["y_f"][r0:r1]), _p(b["mu_f"][r0:r1]),
                  _p(b["rs_f"][r0:r1]), M, D, eps, L.drop_f, _p(seed) if L.drop_f > 0 else None, _fold(b["off"][4], r0 * D), ops._s())
 
-        def layer_fwd2(n, r0, r1, i0, segL):
+        def layer_fwd2(n, r0, r1, i0, segL, fuse_next=False):
             """Both directions of layer n in shared launches (same shapes, their own operands): kernel boundaries cost
             ~5 us each and small launches on two streams do not overlap, so the directions share launches, not streams."""
             L0, L1, b0, b1 = layers[0][n], layers[1][n], B_[0][n], B_[1][n]
@@ -246,7 +244,15 @@ class DecoderStagesFn(torch.autograd.Function):
             # position-wise feed-forward sub-layer
             ops.gemm2(M, F_, D, sl(b0, "y_e"), sl(b1, "y_e"), D, L0.w1, L1.w1, D, sl(b0, "h"), sl(b1, "h"), F_, L0.b1, L1.b1, relu=1)
             ops.gemm2(M, D, F_, sl(b0, "h"), sl(b1, "h"), F_, L0.w2, L1.w2, F_, sl(b0, "o_f"), sl(b1, "o_f"), D, L0.b2, L1.b2)
-            ln2("o_f", "y_e", "y_f", "mu_f", "rs_f", L0.ln_f, L1.ln_f, L0.drop_f, 4)
+            if fuse_next:
+                # the sub-layer's LayerNorm and the cross-direction fusion that feeds layer n + 1, one launch; y_f is not stored
+                nb0, nb1 = B_[0][n + 1]["x"][r0:r1], B_[1][n + 1]["x"][r0:r1]
+                call("sbl_add_layernorm2_fusion_fwd", _p(sl(b0, "o_f")), _p(sl(b1, "o_f")), _p(sl(b0, "y_e")), _p(sl(b1, "y_e")),
+                     _p(L0.ln_f[0]), _p(L1.ln_f[0]), _p(L0.ln_f[1]), _p(L1.ln_f[1]), _p(nb0), _p(nb1), _p(sl(b0, "mu_f")), _p(sl(b1, "mu_f")),
+                     _p(sl(b0, "rs_f")), _p(sl(b1, "rs_f")), N, seg_arr, nseg, D, L0.ln_f[4], L0.drop_f, sp if L0.drop_f > 0 else None,
+                     _fold(b0["off"][4], r0 * D), _fold(b1["off"][4], r0 * D), ops._s())
+            else:
+                ln2("o_f", "y_e", "y_f", "mu_f", "rs_f", L0.ln_f, L1.ln_f, L0.drop_f, 4)
 
         fused_io = getattr(dec, "fuse_stage_io", True) and D == 512 and V <= 64
         for (i0, i1) in stages:
@@ -267,8 +273,9 @@ class DecoderStagesFn(torch.autograd.Function):
                     if p_emb > 0:
                         call("sbl_dropout", _p(dst), _p(B_[d][0]["x"][r0:r1]), M * D, p_emb, _p(seed), _fold(off_emb[d], r0 * D), ops._s())
             for n in range(nl):
+                fuse_next = merged and fused_io and n + 1 < nl
                 if merged:
-                    layer_fwd2(n, r0, r1, i0, segL)
+                    layer_fwd2(n, r0, r1, i0, segL, fuse_next)
                 else:
                     if side is not None:
                         side.wait_stream(main)
@@ -277,8 +284,9 @@ class DecoderStagesFn(torch.autograd.Function):
                             layer_fwd(d, n, r0, r1, i0, segL)
                     if side is not None:
                         main.wait_stream(side)
-                if n + 1 == nl and fused_io:
-                    break          # the last fusion is only ever read at the last positions: it lives in the stage tail below
+                if (n + 1 == nl and fused_io) or fuse_next:
+                    continue       # the last fusion is only ever read at the last positions (stage tail below); the others
+                                   # rode on the LayerNorm launch
                 nxt = [B_[d][n + 1]["x"][r0:r1] if n + 1 < nl else xout[d][r0:r1] for d in (0, 1)]
                 call("sbl_fusion_seg_fwd", _p(B_[0][n]["y_f"][r0:r1]), _p(B_[1][n]["y_f"][r0:r1]), _p(nxt[0]), _p(nxt[1]), N, seg_arr, nseg,
                      D, ops._s())
