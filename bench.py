@@ -18,7 +18,13 @@ seed lives in device memory); the 16 teacher-forcing coins (decoder.py:176) dete
 batched, hence the launch sequence, so --coin-patterns random patterns are drawn (seed 7, same on every rank), one
 graph is captured per pattern and the timed loop cycles through them.
 
+The coin patterns are a stratified sample of Binomial(16, 1/2) (draw_coin_patterns: own-arg-max counts 5..11, mean exactly 8 =
+the expectation; round 2 used four raw draws with mean 7.25, i.e. ~0.45 ms less decoder work per step), the timed loop
+visits each pattern equally often (24 steps over 8 patterns), and `config.per_pattern` reports every pattern's own time.
+
 Prints ONE JSON line (rank 0).  Extra objects:
+  f32_exact    — the same step re-captured and replayed under the exact fp32 MFMA (--precision f32 arithmetic), same run, same
+                 patterns: the like-for-like number next to the split-bf16 headline (N = 1 only)
   roofline     — the dominant kernel family of the step by GPU time.  Every GEMM / convolution launch of the step
                  is timed live, inside replays of the same captured step, by in-kernel s_memrealtime stamps
                  (min start / max end over the launch's workgroups; include/sbl_hip.h sbl_profile_*), i.e. on the
@@ -65,7 +71,7 @@ KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm2?_kernel<Dense
                  4: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, false>",
                  5: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, true>",
                  6: r"(sbl_mfma_gemm_kernel<DenseMC<\d+, true>, ConvGatherMC|sbl_conv_pm_wgrad_kernel)", 7: r"sbl_wgrad_group_kernel"}
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_fetch_write_per_kernel.csv")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_fetch_write_per_kernel.csv")
 T_START = time.perf_counter()
 
 
@@ -609,6 +615,27 @@ def main():
                     f.write("%8.1f us  n=%3d  avg %7.1f us  %6.1f TF  kid %d  %s\n" % (us, n, us / n, fl / us / 1e6, kid, d))
         log(args, "kernel timing done (%d instrumented launches per step)" % len(launches))
 
+    # ---- step time per coin pattern (outside the timed region): the step is linear in the number of own-arg-max coins (one
+    # more sequential decoder stage each), so the fit also says what the round-2 pattern set (mean 7.25 coins) would read
+    per_pattern = None
+    if rank == 0 and world == 1 and graph is not None and not use_split and len(graphs) > 1:
+        per_pattern_ms = []
+        for g_ in graphs:
+            g_.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            g_.replay()
+            g_.replay()
+            torch.cuda.synchronize()
+            per_pattern_ms.append((time.perf_counter() - t1) / 2 * 1e3)
+        cn = np.array([sum(p_) for p_ in patterns], dtype=np.float64)
+        slope, icpt = np.polyfit(cn, np.array(per_pattern_ms), 1) if len(set(cn.tolist())) > 1 else (0.0, per_pattern_ms[0])
+        per_pattern = {"own_argmax_coins": [int(c) for c in cn], "ms": [round(v, 3) for v in per_pattern_ms],
+                       "ms_per_own_argmax_coin": round(float(slope), 3),
+                       "ms_at_7.25_coins": round(float(icpt + 7.25 * slope), 3),      # the mean of round 2's four raw draws
+                       "ms_at_8_coins": round(float(icpt + 8.0 * slope), 3)}
+        log(args, "per-pattern timing done")
+
     # ---- the like-for-like exact-fp32 number, timed in this same run: the matmul precision is baked
     # into a hipGraph at capture, so the step is re-captured under "f32" for every coin pattern and replayed once per
     # pattern after a warm-up replay (rank 0 / N = 1 only; the headline `value` above is untouched by it)
@@ -657,6 +684,8 @@ def main():
                        "allreduce_bytes_per_step": int(4 * sum(n for _, n in exchange.launches) / max(ar_steps[0], 1)) if world > 1 else 0,
                        "loss": round(loss_val, 5)},
         }
+        if per_pattern is not None:
+            out["config"]["per_pattern"] = per_pattern
         if f32_exact is not None:
             out["f32_exact"] = f32_exact
         if fam:

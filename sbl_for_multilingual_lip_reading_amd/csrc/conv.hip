@@ -5,6 +5,8 @@
 //   wgrad : dw[co, (tap,ci)]      = sum_{pix}    dy[pix, co] * x[gather(pix,tap), ci]         (split-K atomics)
 #include "mfma_gemm.h"
 
+int g_sbl_wg_s2_small = 1;      // sbl_set_tuning knob 3: stride-2 weight gradients on 64x64 tiles (128 -> 256: 459 -> 335 us, 256 -> 512: 447 -> 400 us)
+int g_sbl_wg_target = 1536;     // knob 4: their workgroup target (0 = the default rule; same-box step A/B 32.44 / 32.34 / 32.29 ms for 128-tiles / 64-tiles / 64-tiles + 1536)
 static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     SBL_REQUIRE(NIMG > 0 && H > 0 && W > 0, "%s: bad image dims %d %d %d", who, NIMG, H, W);
     SBL_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin >= 16 && Cout >= 16, "%s: Cin=%d Cout=%d must be multiples of 16", who, Cin, Cout);
@@ -139,47 +141,79 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
         // (rows = the class's pixels, k = its taps) does 1/4 of the work of gathering zeros for the other taps.
         const int N = Cin;
         if (KH == 1 && !compact_out) SBL_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)NIMG * H * W * Cin, s));
+        // the classes, heaviest (most taps) first
+        struct Cls { ConvGeom g; int lin[4]; int M, K, ph, pw; };
+        Cls cls[4];
+        int nc = 0;
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {
-                ConvGeom g{NIMG, (H - ph + 1) / 2, (W - pw + 1) / 2, Ho, Wo, Cout, KH, KW, stride, pad, 1, ph, pw, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
-                sbl_geom_finish(g);
-                int lin[4] = {0, 0, 0, 0};
+                Cls c{ConvGeom{NIMG, (H - ph + 1) / 2, (W - pw + 1) / 2, Ho, Wo, Cout, KH, KW, stride, pad, 1, ph, pw, 0, {0, 0, 0, 0}, {0, 0, 0, 0}}, {0, 0, 0, 0}, 0, 0, ph, pw};
+                sbl_geom_finish(c.g);
                 for (int kh = 0; kh < KH; ++kh)
                     for (int kw = 0; kw < KW; ++kw)
                         if (((ph + pad - kh) & 1) == 0 && ((pw + pad - kw) & 1) == 0) {
-                            g.tkh[g.ntaps] = kh; g.tkw[g.ntaps] = kw; lin[g.ntaps] = kh * KW + kw;
-                            ++g.ntaps;
+                            c.g.tkh[c.g.ntaps] = kh; c.g.tkw[c.g.ntaps] = kw; c.lin[c.g.ntaps] = kh * KW + kw;
+                            ++c.g.ntaps;
                         }
-                const int M = NIMG * g.OH * g.OW, K = g.ntaps * Cout;
-                if (g.ntaps == 0 || M == 0) continue;
-                SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
-                const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
-                const float* add = (f.addend && ph == 0 && pw == 0) ? f.addend : nullptr;
-                const int cmap = compact_out ? 0 : 1;
+                c.M = NIMG * c.g.OH * c.g.OW;
+                c.K = c.g.ntaps * Cout;
+                if (c.g.ntaps == 0 || c.M == 0) continue;
+                int at = nc++;
+                while (at > 0 && cls[at - 1].K < c.K) { cls[at] = cls[at - 1]; --at; }
+                cls[at] = c;
+            }
+        if (nc == 0) return 0;
+        SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_DGRAD)};
+        const int cmap = compact_out ? 0 : 1;
+        long t128 = 0, t128x64 = 0;
+        for (int i = 0; i < nc; ++i) {
+            t128 += (long)sbl_cdiv(cls[i].M, 128) * sbl_cdiv(N, 128);
+            t128x64 += (long)sbl_cdiv(cls[i].M, 128) * sbl_cdiv(N, 64);
+        }
+#define SBL_CONV_DGC_GO(BM, BN, EPI_T, MAKE_EPI)                                                              \
+    do {                                                                                                      \
+        ClassSet<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EPI_T> cs;                                          \
+        cs.nclass = nc;                                                                                       \
+        cs.tiles_n = sbl_cdiv(N, BN);                                                                         \
+        long tt = 0;                                                                                          \
+        for (int i = 0; i < SBL_MAX_CLASSES; ++i) {                                                           \
+            const Cls& c = cls[i < nc ? i : 0];                                                               \
+            const float* add = (f.addend && c.ph == 0 && c.pw == 0) ? f.addend : nullptr;                     \
+            cs.al[i] = ConvGatherKC<BM, true>{dy, c.g, c.M};                                                  \
+            cs.bl[i] = DenseKCTaps<BN>{wt, (long)KH * KW * Cout, N, Cout, {c.lin[0], c.lin[1], c.lin[2], c.lin[3]}}; \
+            cs.epi[i] = MAKE_EPI;                                                                             \
+            cs.M[i] = c.M; cs.K[i] = c.K; cs.t0[i] = (int)tt;                                                 \
+            if (i < nc) tt += (long)sbl_cdiv(c.M, BM) * cs.tiles_n;                                           \
+        }                                                                                                     \
+        cs.t0[SBL_MAX_CLASSES] = (int)tt;                                                                     \
+        SBL_REQUIRE(tt < (1L << 30), "sbl_conv2d_dgrad: too many tiles");                                     \
+        SBL_PREC_LAUNCH(SBL_KCL_, dim3((unsigned)tt), s, cs, sc, N);                                          \
+    } while (0)
 #define SBL_CONV_DGC(BM, BN)                                                                                  \
     do {                                                                                                      \
-        ConvGatherKC<BM, true> al{dy, g, M};                                                                  \
-        DenseKCTaps<BN> bl{wt, (long)KH * KW * Cout, N, Cout, {lin[0], lin[1], lin[2], lin[3]}};              \
+        constexpr int BM_ = BM, BN_ = BN;                                                                     \
         if (f.sums) {                                                                                         \
-            EpiStore<0, true, true> e{dx, (long)N, nullptr, 0, f.sums, nullptr, 0, cmap, g.OH, g.OW, H, W, ph, pw, \
-                                      f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2, add, (long)N};          \
-            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, true, true>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+            using E_ = EpiStore<0, true, true>;                                                               \
+            SBL_CONV_DGC_GO(BM, BN, E_, (E_{dx, (long)N, nullptr, 0, f.sums, nullptr, 0, cmap, c.g.OH, c.g.OW, H, W, c.ph, c.pw, \
+                                            f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2, add, (long)N}));   \
         } else if (fused) {                                                                                   \
-            EpiStore<0, false, true> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, cmap, g.OH, g.OW, H, W, ph, pw, \
-                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, add, (long)N}; \
-            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, false, true>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+            using E_ = EpiStore<0, false, true>;                                                              \
+            SBL_CONV_DGC_GO(BM, BN, E_, (E_{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, cmap, c.g.OH, c.g.OW, H, W, c.ph, c.pw, \
+                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, add, (long)N})); \
         } else {                                                                                              \
-            EpiStore<0, false> e{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, cmap, g.OH, g.OW, H, W, ph, pw}; \
-            sbl_launch_gemm<ConvGatherKC<BM, true>, DenseKCTaps<BN>, EpiStore<0, false>, BM, BN>(al, bl, e, M, N, K, 1, s, sc); \
+            using E_ = EpiStore<0, false>;                                                                    \
+            SBL_CONV_DGC_GO(BM, BN, E_, (E_{dx, (long)N, nullptr, 0, nullptr, nullptr, 0, cmap, c.g.OH, c.g.OW, H, W, c.ph, c.pw})); \
         }                                                                                                     \
     } while (0)
-                // (the 128x128 tile with the fused statistics epilogue needs > 168 registers: one wave per SIMD; 128x64 instead)
-                if (N >= 128 && t128 >= 512 && !f.sums) SBL_CONV_DGC(128, 128);
-                else if ((N < 128 || f.sums) && (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 64) >= 512) SBL_CONV_DGC(128, 64);
-                else SBL_CONV_DGC(64, 64);
+#define SBL_KCL_(P) sbl_conv_classes_kernel<ConvGatherKC<BM_, true>, DenseKCTaps<BN_>, E_, BM_, BN_, P>
+        // (the 128x128 tile with the fused statistics epilogue needs > 168 registers: one wave per SIMD; 128x64 instead)
+        if (N >= 128 && t128 >= 512 && !f.sums) SBL_CONV_DGC(128, 128);
+        else if ((N < 128 || f.sums) && t128x64 >= 512) SBL_CONV_DGC(128, 64);
+        else SBL_CONV_DGC(64, 64);
+#undef SBL_KCL_
 #undef SBL_CONV_DGC
-                SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(class)");
-            }
+#undef SBL_CONV_DGC_GO
+        SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(classes)");
         return 0;
     }
     const int M = NIMG * H * W, N = Cin, K = KH * KW * Cout;
@@ -298,8 +332,8 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     // layers 1-4); chunks stay >= 256 pixels
     constexpr int wg_tile = 0;
     constexpr int wg_target_env = 0;
-    const bool big = wg_tile ? wg_tile == 128 : (M >= 128 && N >= 1152);
-    const int wg_target = wg_target_env ? wg_target_env : (big ? 1536 : 3072);
+    const bool big = wg_tile ? wg_tile == 128 : (M >= 128 && N >= 1152 && !(stride == 2 && g_sbl_wg_s2_small));
+    const int wg_target = wg_target_env ? wg_target_env : (g_sbl_wg_target > 0 && stride == 2 ? g_sbl_wg_target : (big ? 1536 : 3072));
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_WGRAD)};
 #define SBL_CONV_WG(BM, BN)                                                                                   \
     do {                                                                                                      \

@@ -524,6 +524,32 @@ __global__ __launch_bounds__(256) void sbl_conv_pm_wgrad_kernel(AL al, BL bl, EP
                                                    by * gridDim.x + bx, 0, 1, false);
 }
 
+// The four parity classes of a stride-2 input gradient (conv.hip) as ONE launch: the classes are independent dense implicit
+// GEMMs with their own row grid, tap list (1 + 2 + 2 + 4 of the nine taps: K = 1, 2, 2, 4 x Cout), output row map and - class
+// (0, 0) only - addend; launched one after the other the short-K classes (8-16 slabs per tile) run mostly prologue and
+// epilogue while the chip drains between launches.  Here a workgroup finds its class from the tile ranges t0[] (heaviest
+// class first) and runs the ordinary tile body; the per-class operand descriptors travel as kernel arguments.
+#define SBL_MAX_CLASSES 4
+template <class AL, class BL, class EPI>
+struct ClassSet {
+    AL al[SBL_MAX_CLASSES];
+    BL bl[SBL_MAX_CLASSES];
+    EPI epi[SBL_MAX_CLASSES];
+    int M[SBL_MAX_CLASSES], K[SBL_MAX_CLASSES], t0[SBL_MAX_CLASSES + 1];
+    int nclass, tiles_n;
+};
+template <class AL, class BL, class EPI, int BM, int BN, int PREC = 0>
+__global__ __launch_bounds__(256) void sbl_conv_classes_kernel(ClassSet<AL, BL, EPI> cs, SplitCtl sc, int N) {
+    const int t = blockIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < SBL_MAX_CLASSES; ++i)
+        if (i < cs.nclass && t >= cs.t0[i]) c = i;
+    const int lt = t - cs.t0[c];
+    const int mx = lt / cs.tiles_n, ny = lt - mx * cs.tiles_n;
+    sbl_gemm_tile<AL, BL, EPI, BM, BN, 1, 2, PREC>(cs.al[c], cs.bl[c], cs.epi[c], sc, cs.M[c], N, mx * BM, ny * BN, 0, cs.K[c], t, 0, 1, false);
+}
+
 template <class AL, class BL, class EPI, int BM, int BN, int KU = 1, int WN = 2>
 static inline void sbl_launch_gemm(const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int splits,
                                    hipStream_t s, SplitCtl sc = SplitCtl{nullptr, nullptr, nullptr, nullptr}) {

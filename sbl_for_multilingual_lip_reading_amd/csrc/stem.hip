@@ -357,27 +357,36 @@ __global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __r
         const float4 be = *reinterpret_cast<const float4*>(beta + c4);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bidx[4] = {0, 0, 0, 0};
+        // branch-free window: the nine 16-byte loads are issued together (clamped addresses; taps that fall into max_pool3d's
+        // padding are masked afterwards).  With a `continue` per out-of-range tap the loads sat in divergent branches and
+        // were issued one by one.
+        float4 v[9];
+        bool ok[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = 2 * ph - 1 + kh;
-            if ((unsigned)ih >= (unsigned)Ho) continue;
+            const int ihc = min(max(ih, 0), Ho - 1);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = 2 * pw - 1 + kw;
-                if ((unsigned)iw >= (unsigned)Wo) continue;
-                const float4 v = *reinterpret_cast<const float4*>(conv + ((img * Ho + ih) * Wo + iw) * 64 + c4);
-                float y[4];
-                y[0] = fmaxf((v.x - mu.x) * is.x * ga.x + be.x, 0.f);
-                y[1] = fmaxf((v.y - mu.y) * is.y * ga.y + be.y, 0.f);
-                y[2] = fmaxf((v.z - mu.z) * is.z * ga.z + be.z, 0.f);
-                y[3] = fmaxf((v.w - mu.w) * is.w * ga.w + be.w, 0.f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (y[q] > best[q]) {
-                        best[q] = y[q];
-                        bidx[q] = kh * 3 + kw;
-                    }
+                const int iwc = min(max(iw, 0), Wo - 1);
+                ok[kh * 3 + kw] = (unsigned)ih < (unsigned)Ho && (unsigned)iw < (unsigned)Wo;
+                v[kh * 3 + kw] = *reinterpret_cast<const float4*>(conv + ((img * Ho + ihc) * Wo + iwc) * 64 + c4);
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float y[4];
+            y[0] = fmaxf((v[t].x - mu.x) * is.x * ga.x + be.x, 0.f);
+            y[1] = fmaxf((v[t].y - mu.y) * is.y * ga.y + be.y, 0.f);
+            y[2] = fmaxf((v[t].z - mu.z) * is.z * ga.z + be.z, 0.f);
+            y[3] = fmaxf((v[t].w - mu.w) * is.w * ga.w + be.w, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[t] && y[q] > best[q]) {
+                    best[q] = y[q];
+                    bidx[q] = t;
+                }
         }
         *reinterpret_cast<float4*>(pooled + (i >> 4) * 64 + c4) = make_float4(best[0], best[1], best[2], best[3]);
         *reinterpret_cast<uint32_t*>(argmax + (i >> 4) * 64 + c4) =
@@ -391,18 +400,24 @@ __global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __r
 __device__ __forceinline__ void stem_gather_g(const float* __restrict__ dpool, const uint8_t* __restrict__ argmax, long img,
                                               int oh, int ow, int Hp, int Wp, int c4, const float y[4], float g[4]) {
     g[0] = g[1] = g[2] = g[3] = 0.f;
-    const int ph_lo = oh >> 1, ph_hi = min(Hp - 1, (oh + 1) >> 1);
-    const int pw_lo = ow >> 1, pw_hi = min(Wp - 1, (ow + 1) >> 1);
-    for (int ph = ph_lo; ph <= ph_hi; ++ph)
-        for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+    // the pixel lies in the pooling windows of rows oh >> 1 and, for odd oh, (oh >> 1) + 1 (columns alike): four candidates
+    // with clamped addresses and validity masks, so that the eight loads are issued together instead of inside loops whose
+    // trip counts depend on the pixel
+    const int ph0 = oh >> 1, pw0 = ow >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ph = min(ph0 + a, Hp - 1), pw = min(pw0 + b, Wp - 1);
+            const bool valid = (a == 0 || ((oh & 1) && ph0 + 1 < Hp)) && (b == 0 || ((ow & 1) && pw0 + 1 < Wp));
             const int pos = (oh - 2 * ph + 1) * 3 + (ow - 2 * pw + 1);
             const long o = ((img * Hp + ph) * Wp + pw) * 64 + c4;
             const uint32_t am = *reinterpret_cast<const uint32_t*>(argmax + o);
             const float4 d = *reinterpret_cast<const float4*>(dpool + o);
-            if ((int)(am & 255) == pos) g[0] += d.x;
-            if ((int)((am >> 8) & 255) == pos) g[1] += d.y;
-            if ((int)((am >> 16) & 255) == pos) g[2] += d.z;
-            if ((int)(am >> 24) == pos) g[3] += d.w;
+            if (valid && (int)(am & 255) == pos) g[0] += d.x;
+            if (valid && (int)((am >> 8) & 255) == pos) g[1] += d.y;
+            if (valid && (int)((am >> 16) & 255) == pos) g[2] += d.z;
+            if (valid && (int)(am >> 24) == pos) g[3] += d.w;
         }
 #pragma unroll
     for (int q = 0; q < 4; ++q)

@@ -10,7 +10,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/pmc_$tag
 rm -rf $o; mkdir -p $o
-B="python3 bench.py --no-cpu-baseline --no-kernel-timing --mode eager --single-stream --steps 1 --warmup 1 --coin-patterns 1"
+B="python3 bench.py --no-cpu-baseline --no-kernel-timing --no-f32-exact --mode eager --single-stream --steps 1 --warmup 1 --coin-patterns 1"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/sf -o r -- $B "$@" > $o/sf.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/sw -o r -- $B "$@" > $o/sw.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/cf -o r -- python3 tools/pmc_calibrate.py $o/known.json > $o/cf.log 2>&1

@@ -7,7 +7,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 6 --warmup 3 "$@" > gpurun_out/${tag}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 bench.py --no-cpu-baseline --no-kernel-timing --no-f32-exact --steps 8 --warmup 3 "$@" > gpurun_out/${tag}_bench.log 2>&1
 trace=$(find $out -name "*kernel_trace.csv" | head -1)
 stats=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 tools/trace_report.py "$trace" -3 16 > gpurun_out/${tag}_timeline.txt
