@@ -66,7 +66,10 @@ int sbl_get_matmul_precision(void);
 /* Measurement knobs (process-wide, read at enqueue time like the precision; results are the same either way).
  * knob 0: wave-group K split of the dense 64x64 split-bf16 tiles (512-thread workgroups), 1 = on (default), 0 = off;
  * knob 1: number of 64x64 output tiles from which a dense product takes 128x128 tiles (default 4096);
- * knob 2: largest tile count of a launch that takes the wave-group K split (default 320). */
+ * knob 2: largest tile count of a launch that takes the wave-group K split (default 320);
+ * knob 3: stride-2 convolution weight gradients on 64x64 tiles (1, default) or by the general rule (0);
+ * knob 4: workgroup target of their split-K (default 1536; 0 = the general rule);
+ * knob 5: patch-resident 3x3 / stride-1 convolution kernel for the large trunk maps (1, default) or the per-tap gathers (0). */
 int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear

@@ -4,7 +4,9 @@
 //   dgrad : dx[pix, ci]           = sum_{tap,co} dy[gather'(pix,tap), co] * wt[ci, tap, co]
 //   wgrad : dw[co, (tap,ci)]      = sum_{pix}    dy[pix, co] * x[gather(pix,tap), ci]         (split-K atomics)
 #include "mfma_gemm.h"
+#include "conv_patch.h"
 
+int g_sbl_conv_patch = 1;        // sbl_set_tuning knob 5: patch-resident 3x3 / stride-1 kernel for the large maps (conv_patch.h)
 int g_sbl_wg_s2_small = 1;      // sbl_set_tuning knob 3: stride-2 weight gradients on 64x64 tiles (128 -> 256: 459 -> 335 us, 256 -> 512: 447 -> 400 us)
 int g_sbl_wg_target = 1536;     // knob 4: their workgroup target (0 = the default rule; same-box step A/B 32.44 / 32.34 / 32.29 ms for 128-tiles / 64-tiles / 64-tiles + 1536)
 static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
@@ -59,6 +61,17 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
+    if (KH == 3 && stride == 1 && !conv_pm_ok(Ho, Wo, KH, stride)) {
+        // large maps (layer 1): the input patch of a tile staged once in LDS for all nine taps (conv_patch.h)
+        bool done;
+        const PatchEpi pe{y, stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (stats) done = sbl_launch_conv_patch<false, 1>(x, w, pe, NIMG, H, W, Cin, Cout, SBL_KID_CONV_FWD, s);
+        else done = sbl_launch_conv_patch<false, 0>(x, w, pe, NIMG, H, W, Cin, Cout, SBL_KID_CONV_FWD, s);
+        if (done) {
+            SBL_LAUNCH_CHECK("sbl_conv2d_fwd(patch)");
+            return 0;
+        }
+    }
     if (conv_pm_ok(Ho, Wo, KH, stride)) {
         // position-major rows: border pixels skip their out-of-bounds taps (mfma_gemm.h, ConvGatherPM)
 #define SBL_KPM_T_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, false>, DenseKCTapList<BN_>, EpiStore<0, true>, BM_, BN_, false, P>
@@ -254,6 +267,18 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
 #undef SBL_KPM_F_
         SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(pm)");
         return 0;
+    }
+    if (KH == 3 && stride == 1) {
+        // large maps: patch-resident kernel with mirrored taps (conv_patch.h); same epilogue functors
+        bool done;
+        const PatchEpi pe{dx, f.sums, f.addend, f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2};
+        if (f.sums) done = sbl_launch_conv_patch<true, 2>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
+        else if (f.addend) done = sbl_launch_conv_patch<true, 3>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
+        else done = sbl_launch_conv_patch<true, 0>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
+        if (done) {
+            SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(patch)");
+            return 0;
+        }
     }
 #define SBL_CONV_DG(BM, BN, WN)                                                                               \
     do {                                                                                                      \

@@ -1,0 +1,292 @@
+// Patch-resident 3x3 / stride-1 convolution for the large trunk maps (ResNet layer 1: 22x22 x 64 channels), split-bf16 modes.
+//
+// The implicit-GEMM kernels of mfma_gemm.h treat every tap as its own K range: each of the nine taps re-gathers its operand
+// from global memory and re-splits it into bf16 planes (9x the loads and conversions; 0.6-0.9 GB fetched per launch for
+// < 60 MB of operands, profiles/r02_pmc_fetch_write_per_kernel.csv).  Here a workgroup owns TR output rows of one image
+// (TR * W <= 256 pixels = 8 MFMA row blocks) and stages the (TR + 2) x (W + 2) x 64-channel input patch ONCE per 64-channel
+// chunk: fp32 -> bf16 planes on the way into LDS (one split per element), zero halo included.  The K loop then walks
+// (tap, 16-channel step): a lane's A operand (pixel l & 31 of a row block, 8 channels) is one 16-byte LDS read per plane at
+// the tap's offset - no global gather, no conversion, no barrier per slab.  The B operand is the tap's 64 x 64 weight block,
+// split once per workgroup into LDS planes with the same padded row layout (fetched into registers during the previous
+// tap, two barriers per tap).  (A first version read the B operand straight from the OHWI weights, 32 bytes per lane at a
+// 2304-byte stride: 64 cache lines per wave-load kept the address unit busy longer than the MFMAs - forward 366 us
+// against 242 us for the per-tap gather kernel.)  4 wavefronts, each 2 pixel blocks x 2 channel blocks of 32x32
+// accumulators (64 output channels per workgroup), 24 MFMAs per 12 16-byte LDS reads at bf16x6.
+//
+// Forward and input gradient are the same kernel: the gradient of a 3x3 / pad-1 / stride-1 convolution is a 3x3 / pad-1
+// convolution of dy with the taps mirrored (tap (kh, kw) reads pixel (oh + 1 - kh, ow + 1 - kw)) and the [Cin][kh][kw][Cout]
+// weight image, so DGRAD only flips the tap offsets.  Epilogues are the engine's EpiStore functors (BN statistics, fused
+// residual / BatchNorm-backward sums), fed with the same (row block, column) accumulator tiles.
+#pragma once
+#include "mfma_gemm.h"
+
+#define SBL_CP_CK 64         // input channels per staged chunk (32: 90 KB of LDS instead of 162, but two staging passes per 64 channels: forward 228 -> 250 us alone)
+#define SBL_CP_PIXB (SBL_CP_CK * 2 + 16)      // bytes per patch pixel and plane: the chunk's channels as bf16 + 16 bytes of padding (conflict-free b128 reads: 80 and 144 bytes both are)
+#define SBL_CP_EROW 68       // floats per pixel row of the epilogue's LDS image (64 channels + 4: conflict-free column writes)
+
+// What the epilogue does with a finished (pixels x 64 channels) tile.  The accumulators are transposed through LDS so that
+// every global access of the epilogue is a 16-byte access of 16 lanes per pixel (the engine's EpiStore works on the MFMA
+// layout: 4-byte accesses, 32 lanes per row - fine beside other resident workgroups, but this kernel runs one workgroup per CU
+// and nothing hides it: 12.5 of 41 us per tile in the first version).
+//   STATS 0: store.   STATS 1: store + per-channel sum / sum of squares (training BatchNorm statistics, video_frontend.py:31-37).
+//   STATS 2: v += addend (optional), store, and the two backward sums of the BatchNorm whose output gradient v is:
+//            g = v * (bs_y > 0), sums (g, g * xhat) - plus (g, g * xhat2) of a second BatchNorm on the same activation (bs_x2).
+//   STATS 3: v += addend, store (a residual gradient without statistics: the first block of layer 1).
+struct PatchEpi {
+    float* out;            // (NIMG*H*W, Nout) row-major
+    double* stats;         // [2 * Nout] (+ [2 * Nout] for bs_x2)
+    const float* add_src;  // laid out like out, or nullptr
+    const float* bs_y;
+    const float* bs_x;
+    const float* bs_mean;
+    const float* bs_inv;
+    const float* bs_x2;
+    const float* bs_mean2;
+    const float* bs_inv2;
+};
+
+template <int NT, bool DGRAD, int STATS>
+__global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wk, PatchEpi epi,
+                                                             int NIMG, int H, int W, int C, int Nout, int TR, int tpi, int ntiles,
+                                                             unsigned long long* stamp) {
+    using Tm = BfTerms<NT>;
+    constexpr int NPL = Tm::NPL;
+    constexpr int CK = SBL_CP_CK, Q4 = CK / 4, WQ = CK / 16;      // chunk channels, float4s per pixel, float4s of a weight row per thread
+    constexpr int WPLANE = 64 * SBL_CP_PIXB;      // one plane of a tap's 64 x CK weight block, rows padded like patch pixels
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    sbl_stamp_begin(stamp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int PW = W + 2, PH = TR + 2;
+    const int plane = PH * PW * SBL_CP_PIXB;
+    unsigned char* wsm = cp_smem + NPL * plane;      // [plane][co 0..63][64 ci] of the current tap
+    const int n0 = blockIdx.y * 64;
+    const long M = (long)NIMG * H * W;
+    // epilogue role: pixel (tid >> 4) + 16 k of the tile, channels ec4 .. ec4 + 3; per-channel sums kept over the workgroup's tiles
+    const int ec4 = (tid & 15) * 4;
+    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, st3[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 emu = make_float4(0.f, 0.f, 0.f, 0.f), eis = emu, emu2 = emu, eis2 = emu;
+    if (STATS == 2) {
+        emu = *reinterpret_cast<const float4*>(epi.bs_mean + n0 + ec4);
+        eis = *reinterpret_cast<const float4*>(epi.bs_inv + n0 + ec4);
+        if (epi.bs_x2) {
+            emu2 = *reinterpret_cast<const float4*>(epi.bs_mean2 + n0 + ec4);
+            eis2 = *reinterpret_cast<const float4*>(epi.bs_inv2 + n0 + ec4);
+        }
+    }
+    // this thread's share of a tap's weight block: output channel tid >> 2, CK / 4 input channels starting at (tid & 3) * CK / 4
+    const float* wsrc = wk + ((long)(n0 + (tid >> 2)) * 9) * C + (tid & 3) * (CK / 4);
+    const int wdst = (tid >> 2) * SBL_CP_PIXB + (tid & 3) * (CK / 2);
+    const int boff = l31 * SBL_CP_PIXB + half * 16;      // B operand: output channel l & 31 of a 32-channel block, 8 input channels
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tpi, r0 = (tile - img * tpi) * TR;
+        const int rows = min(TR, H - r0), npix = rows * W;
+        const long m0 = ((long)img * H + r0) * W;
+        // this lane's two A-operand pixels (clamped: rows past the tile are computed and never stored)
+        int abase[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = min((wave * 2 + i) * 32 + l31, npix - 1);
+            const int pr = p / W, pc = p - pr * W;
+            abase[i] = (pr * PW + pc) * SBL_CP_PIXB + half * 16;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int c0 = 0; c0 < C; c0 += CK) {
+            float4 wreg[WQ];
+#pragma unroll
+            for (int u = 0; u < WQ; ++u) wreg[u] = *reinterpret_cast<const float4*>(wsrc + c0 + u * 4);      // tap 0
+            __syncthreads();      // every wave is done reading the previous patch and weight block
+            // ---- stage the patch chunk: (PH x PW) pixels x 64 channels, 16 float4 per pixel, zero halo; all of a thread's loads
+            // are in flight before the first split
+            const int nq = PH * PW * Q4;
+            constexpr int QB = 10;      // float4s per thread and batch (13 x 24 pixels x 8 float4 = 2496: one batch)
+            for (int q0 = tid; q0 < nq; q0 += 256 * QB) {
+                float4 v[QB];
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const int q = q0 + u * 256;
+                    const int pix = q / Q4, c4 = (q % Q4) * 4;
+                    const int prow = pix / PW, pcol = pix - prow * PW;
+                    const int ih = r0 - 1 + prow, iw = pcol - 1;
+                    const bool ok = q < nq && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) v[u] = *reinterpret_cast<const float4*>(src + (((long)img * H + ih) * W + iw) * C + c0 + c4);
+                }
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const int q = q0 + u * 256;
+                    if (q < nq) {
+                        uint2 pl[NPL];
+                        bf_split4<NPL>(v[u], pl);
+                        const int off = (q / Q4) * SBL_CP_PIXB + (q % Q4) * 8;
+#pragma unroll
+                        for (int t = 0; t < NPL; ++t) *reinterpret_cast<uint2*>(cp_smem + t * plane + off) = pl[t];
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                // the tap's 64 x 64 weight block -> bf16 planes in LDS (loaded into registers during the previous tap)
+#pragma unroll
+                for (int u = 0; u < WQ; ++u) {
+                    uint2 pl[NPL];
+                    bf_split4<NPL>(wreg[u], pl);
+#pragma unroll
+                    for (int t = 0; t < NPL; ++t) *reinterpret_cast<uint2*>(wsm + t * WPLANE + wdst + u * 8) = pl[t];
+                }
+                __syncthreads();      // weight block (and, for tap 0, the patch) complete
+                if (tap < 8) {
+#pragma unroll
+                    for (int u = 0; u < WQ; ++u) wreg[u] = *reinterpret_cast<const float4*>(wsrc + (long)(tap + 1) * C + c0 + u * 4);
+                }
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int toff = ((DGRAD ? 2 - kh : kh) * PW + (DGRAD ? 2 - kw : kw)) * SBL_CP_PIXB;
+                bf16x8 a[2][2][NPL], b[2][2][NPL];      // [register set][block][plane]
+                auto frags = [&](int cs, int set) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < NPL; ++t)
+                            a[set][i][t] = *reinterpret_cast<const bf16x8*>(cp_smem + t * plane + abase[i] + toff + cs * 32);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t = 0; t < NPL; ++t)
+                            b[set][j][t] = *reinterpret_cast<const bf16x8*>(wsm + t * WPLANE + j * 32 * SBL_CP_PIXB + boff + cs * 32);
+                };
+                frags(0, 0);
+#pragma unroll
+                for (int cs = 0; cs < CK / 16; ++cs) {
+                    if (cs + 1 < CK / 16) frags(cs + 1, (cs + 1) & 1);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int t = 0; t < Tm::N; ++t)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs & 1][i][Tm::pa(t)], b[cs & 1][j][Tm::pb(t)], acc[i][j], 0, 0, 0);
+                }
+                __syncthreads();      // every wave has read this tap's weight block
+            }
+        }
+        // ---- epilogue.  The last tap ended on a barrier: the patch area is free; accumulators -> LDS [pixel][68 floats]
+        // (D layout: column l & 31 of block j, rows (r & 3) + 8 (r >> 2) + 4 half of block i), then one 16-byte access per
+        // thread and pixel.  Rows past the tile (the padded rows of its last block) are dropped here.
+        float* ep = reinterpret_cast<float*>(cp_smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = (wave * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    ep[pix * SBL_CP_EROW + j * 32 + l31] = acc[i][j][r];
+                }
+        __syncthreads();
+        for (int pix = tid >> 4; pix < npix; pix += 16) {
+            float4 v = *reinterpret_cast<const float4*>(ep + pix * SBL_CP_EROW + ec4);
+            const long o = (m0 + pix) * Nout + n0 + ec4;
+            if ((STATS == 2 || STATS == 3) && epi.add_src) {
+                const float4 a4 = *reinterpret_cast<const float4*>(epi.add_src + o);
+                v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+            }
+            *reinterpret_cast<float4*>(epi.out + o) = v;
+            if (STATS == 1) {
+                st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
+                st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
+            } else if (STATS == 2) {
+                const float4 yv = *reinterpret_cast<const float4*>(epi.bs_y + o);
+                const float4 xv = *reinterpret_cast<const float4*>(epi.bs_x + o);
+                const float g0 = yv.x > 0.f ? v.x : 0.f, g1 = yv.y > 0.f ? v.y : 0.f, g2 = yv.z > 0.f ? v.z : 0.f, g3 = yv.w > 0.f ? v.w : 0.f;
+                st1[0] += g0; st1[1] += g1; st1[2] += g2; st1[3] += g3;
+                st2[0] += g0 * ((xv.x - emu.x) * eis.x); st2[1] += g1 * ((xv.y - emu.y) * eis.y);
+                st2[2] += g2 * ((xv.z - emu.z) * eis.z); st2[3] += g3 * ((xv.w - emu.w) * eis.w);
+                if (epi.bs_x2) {
+                    const float4 x2 = *reinterpret_cast<const float4*>(epi.bs_x2 + o);
+                    st3[0] += g0 * ((x2.x - emu2.x) * eis2.x); st3[1] += g1 * ((x2.y - emu2.y) * eis2.y);
+                    st3[2] += g2 * ((x2.z - emu2.z) * eis2.z); st3[3] += g3 * ((x2.w - emu2.w) * eis2.w);
+                }
+            }
+        }
+    }
+    if (STATS == 1 || STATS == 2) {
+        // per-channel sums: 16 pixel groups x 16 channel quads -> LDS -> one double atomic per channel and sum
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(cp_smem);      // [3][16 groups][64 channels]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[(0 * 16 + (tid >> 4)) * 64 + ec4 + q] = st1[q];
+            red[(1 * 16 + (tid >> 4)) * 64 + ec4 + q] = st2[q];
+            red[(2 * 16 + (tid >> 4)) * 64 + ec4 + q] = st3[q];
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid >> 6, c = tid & 63;
+            float t = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < 16; ++gq) t += red[(which * 16 + gq) * 64 + c];
+            if (which == 0) {
+                atomicAdd(epi.stats + n0 + c, (double)t);
+                if (STATS == 2 && epi.bs_x2) atomicAdd(epi.stats + 2 * Nout + n0 + c, (double)t);
+            } else if (which == 1) {
+                atomicAdd(epi.stats + Nout + n0 + c, (double)t);
+            } else if (STATS == 2 && epi.bs_x2) {
+                atomicAdd(epi.stats + 3 * Nout + n0 + c, (double)t);
+            }
+        }
+    }
+    sbl_stamp_end(stamp);
+}
+
+// Tile rows for an H x W map: the largest TR <= H with TR * W <= 256 whose patch fits 160 KB of LDS at three planes
+// (0: the map does not take this path).
+static inline int sbl_conv_patch_rows(int H, int W, int nplanes) {
+    int best = 0;
+    for (int tr = 1; tr <= H; ++tr)
+        if (tr * W <= 256 && ((long)(tr + 2) * (W + 2) + 64) * SBL_CP_PIXB * nplanes <= 160 * 1024) best = tr;
+    // prefer an even split of the image (22 rows: 11 + 11, not 11 + 11 with a ragged rest)
+    if (best > 0) {
+        const int parts = sbl_cdiv(H, best);
+        best = sbl_cdiv(H, parts);
+    }
+    return best;
+}
+
+extern int g_sbl_conv_patch;      // sbl_set_tuning knob 5 (1 = on)
+template <bool DGRAD, int STATS>
+static inline bool sbl_launch_conv_patch(const float* src, const float* wk, const PatchEpi& epi, int NIMG, int H, int W, int C, int Nout,
+                                         int kid, hipStream_t s) {
+    if (!g_sbl_conv_patch || g_sbl_prec == 0 || C % SBL_CP_CK != 0 || Nout % 64 != 0) return false;
+    const int npl = g_sbl_prec == 6 ? 3 : g_sbl_prec == 3 ? 2 : 1;
+    const int TR = sbl_conv_patch_rows(H, W, npl);
+    if (TR < 4 || TR * W < 160) return false;      // small maps keep the position-major kernels (too few pixels per tile)
+    const int tpi = sbl_cdiv(H, TR), ntiles = NIMG * tpi;
+    size_t lds = (size_t)npl * ((TR + 2) * (W + 2) + 64) * SBL_CP_PIXB;
+    if (lds < (size_t)256 * SBL_CP_EROW * 4) lds = (size_t)256 * SBL_CP_EROW * 4;      // the epilogue's image of the tile
+    const int gx = ntiles < 256 ? ntiles : 256;      // persistent: one workgroup per CU (the patch takes most of its LDS)
+    const dim3 grid(gx, Nout / 64);
+    unsigned long long* stamp = sbl_next_stamp_slot(kid);
+#define SBL_CP_GO(P)                                                                                                           \
+    do {                                                                                                                       \
+        static bool set_##P[64] = {false};                                                                                     \
+        int dev = 0;                                                                                                           \
+        if (hipGetDevice(&dev) != hipSuccess) return false;                                                                    \
+        if (!set_##P[dev & 63]) {                                                                                              \
+            if (hipFuncSetAttribute((const void*)sbl_conv_patch_kernel<P, DGRAD, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false; \
+            set_##P[dev & 63] = true;                                                                                          \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((sbl_conv_patch_kernel<P, DGRAD, STATS>), grid, dim3(256), lds, s, src, wk, epi, NIMG, H, W, C, Nout, TR, tpi, ntiles, stamp); \
+    } while (0)
+    if (g_sbl_prec == 6) SBL_CP_GO(6);
+    else if (g_sbl_prec == 3) SBL_CP_GO(3);
+    else SBL_CP_GO(1);
+#undef SBL_CP_GO
+    return true;
+}

@@ -58,10 +58,10 @@ int g_sbl_wave_ksplit = 1;
 int g_sbl_ksplit_tiles = 320;      // knob 2 (same-box A/B of the whole step: 0 -> 32.99, 320 -> 32.81, 768 -> 32.99 ms)
 int g_sbl_big_min = 4096;          // knob 1
 extern "C" int sbl_set_tuning(int knob, int value) {
-    extern int g_sbl_wg_s2_small, g_sbl_wg_target;
-    if (knob == 3 || knob == 4) {
+    extern int g_sbl_wg_s2_small, g_sbl_wg_target, g_sbl_conv_patch;
+    if (knob >= 3 && knob <= 5) {
         SBL_REQUIRE(value >= 0, "sbl_set_tuning: negative value");
-        (knob == 3 ? g_sbl_wg_s2_small : g_sbl_wg_target) = value;
+        (knob == 3 ? g_sbl_wg_s2_small : knob == 4 ? g_sbl_wg_target : g_sbl_conv_patch) = value;
         return 0;
     }
     SBL_REQUIRE(knob >= 0 && knob <= 2 && value >= 0, "sbl_set_tuning: unknown knob %d / value %d (0 = wave-group K split on/off, 1 = 64x64-tile count from which dense products take 128x128 tiles, 2 = largest tile count that takes the wave-group K split)", knob, value);

@@ -196,6 +196,8 @@ def _nhwc(t):
     (3, 22, 22, 64, 64, 3, 1), (5, 22, 22, 64, 128, 3, 2), (5, 22, 22, 64, 128, 1, 2), (4, 11, 11, 128, 128, 3, 1),
     (6, 6, 6, 256, 512, 3, 2), (7, 3, 3, 512, 512, 3, 1), (2, 7, 5, 64, 64, 3, 2), (40, 22, 22, 64, 64, 3, 1),
     (20, 22, 22, 128, 128, 3, 1),
+    # patch-resident path (conv_patch.h) at config 5's 28x28 maps (4 tiles of 7 rows) and at a ragged split (20 rows: 10 + 10)
+    (3, 28, 28, 64, 64, 3, 1), (2, 20, 24, 64, 128, 3, 1), (300, 22, 22, 64, 64, 3, 1),
     # position-major path (3x3 / stride 1, maps of <= 36 pixels): tiles inside one position, straddling two, covering many
     (150, 3, 3, 512, 512, 3, 1), (130, 6, 6, 256, 256, 3, 1), (70, 6, 6, 256, 256, 3, 1), (33, 4, 5, 256, 128, 3, 1),
     (9, 5, 4, 128, 256, 3, 1)])
