@@ -54,11 +54,17 @@ extern "C" int sbl_set_matmul_precision(int terms) {
     return 0;
 }
 extern "C" int sbl_get_matmul_precision(void) { return g_sbl_prec; }
+int g_sbl_group_cap = 0;           // knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile)
 int g_sbl_wave_ksplit = 1;
 int g_sbl_ksplit_tiles = 320;      // knob 2 (same-box A/B of the whole step: 0 -> 32.99, 320 -> 32.81, 768 -> 32.99 ms)
 int g_sbl_big_min = 4096;          // knob 1
 extern "C" int sbl_set_tuning(int knob, int value) {
     extern int g_sbl_wg_s2_small, g_sbl_wg_target, g_sbl_conv_patch;
+    if (knob == 6) {
+        SBL_REQUIRE(value >= 0, "sbl_set_tuning: negative value");
+        g_sbl_group_cap = value;
+        return 0;
+    }
     if (knob >= 3 && knob <= 5) {
         SBL_REQUIRE(value >= 0, "sbl_set_tuning: negative value");
         (knob == 3 ? g_sbl_wg_s2_small : knob == 4 ? g_sbl_wg_target : g_sbl_conv_patch) = value;
@@ -352,7 +358,7 @@ __global__ void group_write_kernel(GroupWrite w, GroupProb* table, int first, in
     if (i < count) table[first + i] = w.p[i];
 }
 struct GroupCommon {
-    int nprob, nseg, K;
+    int nprob, nseg, K, ntiles;
     int kcum[SBL_MAX_KSEG + 1];
 };
 // ONESEG: every problem's K rows are one contiguous block (the stage-batched decoder backward, the encoder): plain
@@ -361,9 +367,12 @@ struct GroupCommon {
 template <bool ONESEG, int PREC>
 __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* __restrict__ table, GroupCommon gc,
                                                               unsigned long long* stamp) {
+    // (gridDim.x may be capped below the tile count - sbl_set_tuning knob 6: the workgroups then walk the tiles, so that the
+    // launch takes a bounded share of the CUs while a dependent chain of small kernels runs on the other stream)
+  for (int t = blockIdx.x; t < gc.ntiles; t += gridDim.x) {
+    if (t != (int)blockIdx.x) __syncthreads();      // the previous tile's LDS reads are done
     // problem of this tile: binary search over tile0 (ascending), workgroup-uniform
     int lo = 0, hi = gc.nprob - 1;
-    const int t = blockIdx.x;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (table[mid].tile0 <= t) lo = mid; else hi = mid - 1;
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(256) void sbl_wgrad_group_kernel(const GroupProb* _
         sbl_gemm_tile<SegMC<128, true>, SegMC<128, true>, EpiStore<1, false>, 128, 128, 1, 2, PREC>(al, bl, e, sc, g.M, g.N, tx * 128,
                                                                                                   ty * 128, 0, gc.K, 0, 0, 1, ty == 0);
     }
+  }
 }
 
 extern "C" long sbl_wgrad_group_table_bytes(int nprob) { return (long)sizeof(GroupProb) * (nprob > 0 ? nprob : 0); }
@@ -446,6 +456,8 @@ extern "C" int sbl_wgrad_group_f32(int nprob, int nseg, const int* seg_rows, con
         hipLaunchKernelGGL(group_write_kernel, dim3(1), dim3(64), 0, s, w, tab, first, count);
     }
     SBL_REQUIRE(tiles < (1L << 30), "sbl_wgrad_group_f32: too many tiles");
+    gc.ntiles = (int)tiles;
+    if (g_sbl_group_cap > 0 && tiles > g_sbl_group_cap) tiles = g_sbl_group_cap;      // workgroups of the launch (they walk the tiles)
 #define SBL_KG1_(P) sbl_wgrad_group_kernel<true, P>
 #define SBL_KG0_(P) sbl_wgrad_group_kernel<false, P>
     if (nseg == 1)

@@ -307,7 +307,7 @@ class DecoderStagesFn(torch.autograd.Function):
         ctx.state = dict(N=N, T=T, D=D, H=H, HD=HD, F=F_, V=V, ML=ML, nl=nl, R=R, layers=layers, B=B_, xout=xout, last=last, ys=ys,
                          heads=heads, g_heads=(ops._gbuf(heads[0]), ops._gbuf(heads[1])), g_emb=ops._gbuf(emb), seed=seed,
                          p_emb=p_emb, off_emb=off_emb, streams=streams, two=side is not None, enc2=enc2, training=training,
-                         kv_fused=kv_fused, ldkv=ldkv, kv_order=kv_order)
+                         kv_fused=kv_fused, ldkv=ldkv, kv_order=kv_order, defer_wgrads=bool(getattr(dec, "defer_weight_grads", False)))
         ctx.set_materialize_grads(False)
         dec.last_ys = ys
         # (ML*N, V) step-major -> (N, ML, V) views
@@ -444,17 +444,27 @@ class DecoderStagesFn(torch.autograd.Function):
         else:
             denc[0].add_(denc[1])
         # ---- every weight gradient of the decoder: one grouped launch per row count (R rows; N*T rows for K/V)
-        _DeferredWeightGrads(wg, {id(L.g_wkv): N * T for d in (0, 1) for L in layers[d]}, R, main, side).arm()
+        deferred = _DeferredWeightGrads(wg, {id(L.g_wkv): N * T for d in (0, 1) for L in layers[d]}, R, main, side)
+        # Issued right here (the grouped launch then runs beside the encoder backward, a dependent chain of 928-row products
+        # that cannot fill the chip), or - dec.defer_weight_grads = True - when backward has passed the encoder.  Same-box A/B
+        # of the whole step: 31.46 ms here against 31.95 ms deferred: deferring makes the encoder's own launches 2-3x faster
+        # (they no longer share the CUs with 2688 tiles) but leaves the chip idle under them, and the grouped launch then
+        # competes with the throughput-bound frontend backward instead.  Capping the grouped launch's grid (sbl_set_tuning
+        # knob 6) to 128 / 192 workgroups beside the encoder backward: 33.69 / 32.01 ms.
+        if S.get("defer_wgrads", False):
+            deferred.arm()
+        else:
+            deferred.flush()
         ctx.state = None
         return denc[0].view(N, T, D), None, None, None, None, None
 
 
 class _DeferredWeightGrads:
-    """The decoder's collected weight gradients, issued (grouped launches on the side stream) when backward has passed the
-    ENCODER: the encoder backward is a dependent chain of 928-row products that cannot fill the chip, and beside the
-    2688-tile grouped launch its kernels ran at a tenth of their speed (6-28 TF, profiles/r02_bench_launch_shapes.txt);
-    the frontend backward that follows is throughput-bound and shares the chip gracefully.  Triggers, whichever comes
-    first: ops.flush_deferred() - called from the hook on the encoder INPUT's gradient (encoder.py) and by
+    """The decoder's collected weight gradients (grouped launches on the side stream).  flush() issues them; arm() postpones
+    that until backward has passed the ENCODER (optional, dec.defer_weight_grads; measured slower for the whole step, see
+    DecoderStagesFn.backward): beside the 2688-tile grouped launch the encoder's 928-row products run at a tenth of their
+    speed (6-28 TF, profiles/r02_bench_launch_shapes.txt), but without it the chip idles under them.  Triggers of an armed
+    instance, whichever comes first: ops.flush_deferred() - called from the hook on the encoder INPUT's gradient (encoder.py) and by
     dp.GradientExchange before it all-reduces the decoder segment (N > 1: the exchange must see finished gradients, so
     there the flush stays where it was) - or the end-of-backward engine callback (frozen encoder)."""
 
