@@ -274,7 +274,7 @@ __device__ __forceinline__ float grp_sum_lo(float v) {   // across n inside a 16
 }
 
 struct SmallProb {
-    int Lq, Lk, b, h;
+    int Lq, Lk, b, h, qoff;      // qoff: index of the tile's first query inside its sequence (query-tile mode), else 0
     long qrow, krow, pbase;
 };
 __device__ __forceinline__ SmallProb small_prob(int prob, int B, int H, const SegDesc& segs, int Lk_fixed) {
@@ -291,6 +291,12 @@ __device__ __forceinline__ SmallProb small_prob(int prob, int B, int H, const Se
     P.qrow = ro + (long)P.b * Lq;
     P.krow = Lk_fixed > 0 ? (long)P.b * P.Lk : P.qrow;
     P.pbase = po + ((long)P.h * B + P.b) * Lq * P.Lk;
+    P.qoff = 0;
+    if (segs.qtile) {      // query tiles of one self-attention over qtile (= Lk_fixed) rows: all tiles read the sequence's own keys
+        P.qoff = ro;
+        P.qrow = (long)P.b * segs.qtile + ro;
+        P.pbase = ((long)P.h * B + P.b) * segs.qtile * P.Lk + po;
+    }
     return P;
 }
 
@@ -323,7 +329,7 @@ __device__ __forceinline__ void attention_small_fwd_body(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * t + 4 * g + r;
-                const bool valid = j < Lk && !(causal && j > n);
+                const bool valid = j < Lk && !(causal && j > n + P.qoff);
                 s[t][r] = valid ? acc[r] * scale : -INFINITY;
                 m = fmaxf(m, s[t][r]);
             }
@@ -622,6 +628,23 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
     }
 }
 
+// Self-attention over 17..32 rows (the encoder's 29 frames): two query tiles of <= 16 rows per (batch, head), each a
+// one-wavefront problem over all of the sequence's keys; in backward the tiles' dK / dV meet in LDS like the segments of a
+// cross-attention run (SHARED_KV).  attention.py:72-83 at the encoder's size without the 256-thread / 50-100 KB workgroup.
+static bool at_qtile_ok(const SegDesc& d, int Lk_fixed, int mask_kind) {
+    return d.nseg == 1 && mask_kind != 2 && d.L[0] > 16 && d.L[0] <= 32 && Lk_fixed <= 32;
+}
+static SegDesc at_qtile_desc(int L, int Lk) {      // L query rows (two tiles), Lk keys
+    SegDesc t;
+    t.nseg = 2;
+    t.qtile = L;
+    for (int s = 0; s < SBL_MAX_SEG; ++s) {
+        t.L[s] = s == 0 ? 16 : (s == 1 ? L - 16 : 0);
+        t.row_off[s] = s < 2 ? 16 * s : 0;
+        t.p_off[s] = s < 2 ? 16 * s * Lk : 0;
+    }
+    return t;
+}
 static bool at_small_ok(const SegDesc& d, int Lk_fixed, int mask_kind) {
     constexpr int enabled = 1;
     if (!enabled || mask_kind == 2 || Lk_fixed > 32) return false;
@@ -681,6 +704,16 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
                            ldv, o, ldo, p_out, mask_kind == 1, B, H, d, Lk_fixed, scale,
                            drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
         SBL_LAUNCH_CHECK("sbl_attention_fwd(small)");
+        return 0;
+    }
+    if (at_qtile_ok(d, Lk_fixed, mask_kind) && sbl_aligned16(o)) {
+        const int Lk = Lk_fixed > 0 ? Lk_fixed : d.L[0];
+        const SegDesc t = at_qtile_desc(d.L[0], Lk);
+        const int nprob = 2 * B * H;
+        hipLaunchKernelGGL(attention_small_fwd_kernel, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
+                           ldv, o, ldo, p_out, mask_kind == 1, B, H, t, Lk, scale,
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+        SBL_LAUNCH_CHECK("sbl_attention_fwd(query tiles)");
         return 0;
     }
     const int sz = at_rows_sz(d, nseg, Lk_fixed);
@@ -755,6 +788,17 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
                                lddo, q, ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
                                drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
         SBL_LAUNCH_CHECK("sbl_attention_bwd(small)");
+        return 0;
+    }
+    if (at_qtile_ok(d, Lk_fixed, 0) && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && sbl_aligned16(dq) && sbl_aligned16(dk) && sbl_aligned16(dv)) {
+        const int Lk = Lk_fixed > 0 ? Lk_fixed : d.L[0];
+        const SegDesc t = at_qtile_desc(d.L[0], Lk);
+        static bool attr_set3[64] = {false};
+        if (int e = at_attr((const void*)attention_small_bwd_kernel<true>, 8 * 16384, attr_set3)) return e;
+        hipLaunchKernelGGL(attention_small_bwd_kernel<true>, dim3(B * H), dim3(128), (size_t)2 * 16384, (hipStream_t)stream, dout, lddo, q, ldq, k,
+                           ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, t, Lk, scale,
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, 2 * B * H);
+        SBL_LAUNCH_CHECK("sbl_attention_bwd(query tiles)");
         return 0;
     }
     if (Lk_fixed > 0 && nseg > 1) {      // shared keys: the workgroup kernel accumulates dK / dV with float atomics

@@ -65,11 +65,14 @@ struct SegDesc {
     int L[SBL_MAX_SEG];
     int row_off[SBL_MAX_SEG];
     int p_off[SBL_MAX_SEG];     // offset (floats) of the segment's attention-probability block
+    int qtile;                  // 0, or L: the "segments" are 16-row QUERY TILES of one self-attention over L rows per batch entry
+                                // (row_off / p_off are then offsets inside a sequence / inside a (head, batch) probability block)
 };
 // host: build from an array of lengths; returns total rows (or -1 on bad input)
 static inline long sbl_make_segs(SegDesc& d, const int* seg_L, int nseg, int B, int H, int Lk_fixed) {
     if (nseg < 1 || nseg > SBL_MAX_SEG || !seg_L) return -1;
     d.nseg = nseg;
+    d.qtile = 0;
     long rows = 0, p = 0;
     for (int s = 0; s < SBL_MAX_SEG; ++s) {
         d.L[s] = s < nseg ? seg_L[s] : 0;

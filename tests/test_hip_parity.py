@@ -405,7 +405,9 @@ def test_add_layernorm(ops):
 
 
 @pytest.mark.parametrize("Lq,Lk,mask", [(29, 29, None), (9, 9, "causal"), (1, 1, "causal"), (16, 29, None), (64, 64, None),
-                                        (33, 64, None), (7, 11, "tensor"), (16, 16, "causal")])
+                                        (33, 64, None), (7, 11, "tensor"), (16, 16, "causal"),
+                                        # 17..32 queries: two query tiles on the one-wavefront kernels (the encoder's 29 frames)
+                                        (29, 29, "causal"), (20, 32, None), (17, 5, None), (32, 32, "causal"), (29, 29, "tensor")])
 def test_attention_core(ops, Lq, Lk, mask):
     from oracle import sbl_oracle as O
     B, H = 3, 8
@@ -691,7 +693,10 @@ def _seg_attention_bwd(ops, do, q, k, v, p, B, H, segL, Lk_fixed, drop_p, seed, 
 @pytest.mark.parametrize("segL,Lk_fixed,causal", [((3, 16, 9), 0, True), ((1, 2), 0, False), ((5, 16, 7, 1), 29, False),
                                                   ((16,), 32, False), ((4,), 13, False), ((12, 20), 29, False),
                                                   ((1, 2, 3, 4, 5, 6, 7, 8, 9, 10), 29, False),
-                                                  (tuple(range(1, 17)), 29, False), ((16, 3, 1, 9, 2, 2, 7, 5, 11), 32, False)])
+                                                  (tuple(range(1, 17)), 29, False), ((16, 3, 1, 9, 2, 2, 7, 5, 11), 32, False),
+                                                  # query tiles (one segment of 17..32 rows): self-attention with and without the
+                                                  # causal mask, cross-attention to 32 keys - including the dropout properties below
+                                                  ((29,), 0, False), ((29,), 0, True), ((20,), 32, False)])
 def test_segmented_attention_decoder_sizes(ops, segL, Lk_fixed, causal):
     """The ragged attention entry points at decoder sizes (<= 16 queries, <= 32 keys take the one-wavefront-per-problem
     kernels; the (12, 20) case the workgroup kernel) against fp64 torch, forward and backward, plus the dropout path
