@@ -6,7 +6,8 @@
 #include "mfma_gemm.h"
 #include "conv_patch.h"
 
-int g_sbl_conv_patch = 1;        // sbl_set_tuning knob 5: patch-resident 3x3 / stride-1 kernel for the large maps (conv_patch.h)
+int g_sbl_conv_patch = 2;        // sbl_set_tuning knob 5: patch-resident 3x3 / stride-1 kernel for the large maps (conv_patch.h): 0 off,
+                                 // 1 padded 64-channel rows (one workgroup per CU), 2 swizzled 32-channel rows (two per CU; default)
 int g_sbl_wg_s2_small = 1;      // sbl_set_tuning knob 3: stride-2 weight gradients on 64x64 tiles (128 -> 256: 459 -> 335 us, 256 -> 512: 447 -> 400 us)
 int g_sbl_wg_target = 1536;     // knob 4: their workgroup target (0 = the default rule; same-box step A/B 32.44 / 32.34 / 32.29 ms for 128-tiles / 64-tiles / 64-tiles + 1536)
 static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

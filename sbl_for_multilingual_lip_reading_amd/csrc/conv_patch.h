@@ -20,8 +20,18 @@
 #pragma once
 #include "mfma_gemm.h"
 
-#define SBL_CP_CK 64         // input channels per staged chunk (32: 90 KB of LDS instead of 162, but two staging passes per 64 channels: forward 228 -> 250 us alone)
-#define SBL_CP_PIXB (SBL_CP_CK * 2 + 16)      // bytes per patch pixel and plane: the chunk's channels as bf16 + 16 bytes of padding (conflict-free b128 reads: 80 and 144 bytes both are)
+// Two LDS layouts of a patch pixel / weight row (per plane):
+//   SW = false: 64 channels + 16 bytes of padding (144 B stride: conflict-free 16-byte reads); 162 KB at 11 x 22 pixels, ONE
+//               workgroup per CU.
+//   SW = true : 32 channels, no padding (64 B), the four 16-byte chunks of a row XOR-swizzled with bits 2-3 of the row index
+//               (consecutive rows then spread over all 64 banks): 72 KB, TWO workgroups per CU, so that one workgroup's patch
+//               staging and epilogue run under the other's MFMAs; twice the staging passes and barriers per 64 channels.
+#define SBL_CP_CKV(SW) ((SW) ? 32 : 64)
+#define SBL_CP_PIXBV(SW) ((SW) ? 64 : 144)
+template <bool SW>
+__device__ __forceinline__ int cp_addr(int row, int chunk) {      // byte offset of 16-byte chunk `chunk` of row `row` inside a plane
+    return SW ? row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4) : row * 144 + (chunk << 4);
+}
 #define SBL_CP_EROW 68       // floats per pixel row of the epilogue's LDS image (64 channels + 4: conflict-free column writes)
 
 // What the epilogue does with a finished (pixels x 64 channels) tile.  The accumulators are transposed through LDS so that
@@ -45,19 +55,19 @@ struct PatchEpi {
     const float* bs_inv2;
 };
 
-template <int NT, bool DGRAD, int STATS>
+template <int NT, bool DGRAD, int STATS, bool SW>
 __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wk, PatchEpi epi,
                                                              int NIMG, int H, int W, int C, int Nout, int TR, int tpi, int ntiles,
                                                              unsigned long long* stamp) {
     using Tm = BfTerms<NT>;
     constexpr int NPL = Tm::NPL;
-    constexpr int CK = SBL_CP_CK, Q4 = CK / 4, WQ = CK / 16;      // chunk channels, float4s per pixel, float4s of a weight row per thread
-    constexpr int WPLANE = 64 * SBL_CP_PIXB;      // one plane of a tap's 64 x CK weight block, rows padded like patch pixels
+    constexpr int CK = SBL_CP_CKV(SW), PIXB = SBL_CP_PIXBV(SW), Q4 = CK / 4, WQ = CK / 16;      // chunk channels, row bytes, float4s per pixel, float4s of a weight row per thread
+    constexpr int WPLANE = 64 * PIXB;      // one plane of a tap's 64 x CK weight block, rows padded like patch pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
     sbl_stamp_begin(stamp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int PW = W + 2, PH = TR + 2;
-    const int plane = PH * PW * SBL_CP_PIXB;
+    const int plane = PH * PW * PIXB;
     unsigned char* wsm = cp_smem + NPL * plane;      // [plane][co 0..63][64 ci] of the current tap
     const int n0 = blockIdx.y * 64;
     const long M = (long)NIMG * H * W;
@@ -75,20 +85,20 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
     }
     // this thread's share of a tap's weight block: output channel tid >> 2, CK / 4 input channels starting at (tid & 3) * CK / 4
     const float* wsrc = wk + ((long)(n0 + (tid >> 2)) * 9) * C + (tid & 3) * (CK / 4);
-    const int wdst = (tid >> 2) * SBL_CP_PIXB + (tid & 3) * (CK / 2);
-    const int boff = l31 * SBL_CP_PIXB + half * 16;      // B operand: output channel l & 31 of a 32-channel block, 8 input channels
+    // (a thread's WQ float4s of a weight row = chunks (tid & 3) * WQ / 2 ... : WQ = 4 -> two chunks, WQ = 2 -> one chunk)
+    const int wrow = tid >> 2;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int img = tile / tpi, r0 = (tile - img * tpi) * TR;
         const int rows = min(TR, H - r0), npix = rows * W;
         const long m0 = ((long)img * H + r0) * W;
         // this lane's two A-operand pixels (clamped: rows past the tile are computed and never stored)
-        int abase[2];
+        int arow[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = min((wave * 2 + i) * 32 + l31, npix - 1);
             const int pr = p / W, pc = p - pr * W;
-            abase[i] = (pr * PW + pc) * SBL_CP_PIXB + half * 16;
+            arow[i] = pr * PW + pc;
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
                     if (q < nq) {
                         uint2 pl[NPL];
                         bf_split4<NPL>(v[u], pl);
-                        const int off = (q / Q4) * SBL_CP_PIXB + (q % Q4) * 8;
+                        const int off = cp_addr<SW>(q / Q4, (q % Q4) >> 1) + ((q % Q4) & 1) * 8;
 #pragma unroll
                         for (int t = 0; t < NPL; ++t) *reinterpret_cast<uint2*>(cp_smem + t * plane + off) = pl[t];
                     }
@@ -139,7 +149,8 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
                     uint2 pl[NPL];
                     bf_split4<NPL>(wreg[u], pl);
 #pragma unroll
-                    for (int t = 0; t < NPL; ++t) *reinterpret_cast<uint2*>(wsm + t * WPLANE + wdst + u * 8) = pl[t];
+                    for (int t = 0; t < NPL; ++t)
+                        *reinterpret_cast<uint2*>(wsm + t * WPLANE + cp_addr<SW>(wrow, ((tid & 3) * WQ + u) >> 1) + (u & 1) * 8) = pl[t];
                 }
                 __syncthreads();      // weight block (and, for tap 0, the patch) complete
                 if (tap < 8) {
@@ -147,19 +158,19 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
                     for (int u = 0; u < WQ; ++u) wreg[u] = *reinterpret_cast<const float4*>(wsrc + (long)(tap + 1) * C + c0 + u * 4);
                 }
                 const int kh = tap / 3, kw = tap - kh * 3;
-                const int toff = ((DGRAD ? 2 - kh : kh) * PW + (DGRAD ? 2 - kw : kw)) * SBL_CP_PIXB;
+                const int trow = (DGRAD ? 2 - kh : kh) * PW + (DGRAD ? 2 - kw : kw);
                 bf16x8 a[2][2][NPL], b[2][2][NPL];      // [register set][block][plane]
                 auto frags = [&](int cs, int set) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int t = 0; t < NPL; ++t)
-                            a[set][i][t] = *reinterpret_cast<const bf16x8*>(cp_smem + t * plane + abase[i] + toff + cs * 32);
+                            a[set][i][t] = *reinterpret_cast<const bf16x8*>(cp_smem + t * plane + cp_addr<SW>(arow[i] + trow, cs * 2 + half));
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int t = 0; t < NPL; ++t)
-                            b[set][j][t] = *reinterpret_cast<const bf16x8*>(wsm + t * WPLANE + j * 32 * SBL_CP_PIXB + boff + cs * 32);
+                            b[set][j][t] = *reinterpret_cast<const bf16x8*>(wsm + t * WPLANE + cp_addr<SW>(j * 32 + l31, cs * 2 + half));
                 };
                 frags(0, 0);
 #pragma unroll
@@ -247,10 +258,10 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
 
 // Tile rows for an H x W map: the largest TR <= H with TR * W <= 256 whose patch fits 160 KB of LDS at three planes
 // (0: the map does not take this path).
-static inline int sbl_conv_patch_rows(int H, int W, int nplanes) {
+static inline int sbl_conv_patch_rows(int H, int W, int nplanes, bool sw) {
     int best = 0;
     for (int tr = 1; tr <= H; ++tr)
-        if (tr * W <= 256 && ((long)(tr + 2) * (W + 2) + 64) * SBL_CP_PIXB * nplanes <= 160 * 1024) best = tr;
+        if (tr * W <= 256 && ((long)(tr + 2) * (W + 2) + 64) * SBL_CP_PIXBV(sw) * nplanes <= (sw ? 80 : 160) * 1024) best = tr;
     // prefer an even split of the image (22 rows: 11 + 11, not 11 + 11 with a ragged rest)
     if (best > 0) {
         const int parts = sbl_cdiv(H, best);
@@ -263,30 +274,38 @@ extern int g_sbl_conv_patch;      // sbl_set_tuning knob 5 (1 = on)
 template <bool DGRAD, int STATS>
 static inline bool sbl_launch_conv_patch(const float* src, const float* wk, const PatchEpi& epi, int NIMG, int H, int W, int C, int Nout,
                                          int kid, hipStream_t s) {
-    if (!g_sbl_conv_patch || g_sbl_prec == 0 || C % SBL_CP_CK != 0 || Nout % 64 != 0) return false;
+    const bool sw = g_sbl_conv_patch == 2;      // knob 5: 1 = padded 64-channel rows (one workgroup per CU), 2 = swizzled 32-channel rows (two)
+    if (!g_sbl_conv_patch || g_sbl_prec == 0 || C % 64 != 0 || Nout % 64 != 0) return false;
     const int npl = g_sbl_prec == 6 ? 3 : g_sbl_prec == 3 ? 2 : 1;
-    const int TR = sbl_conv_patch_rows(H, W, npl);
+    const int TR = sbl_conv_patch_rows(H, W, npl, sw);
     if (TR < 4 || TR * W < 160) return false;      // small maps keep the position-major kernels (too few pixels per tile)
     const int tpi = sbl_cdiv(H, TR), ntiles = NIMG * tpi;
-    size_t lds = (size_t)npl * ((TR + 2) * (W + 2) + 64) * SBL_CP_PIXB;
+    size_t lds = (size_t)npl * ((TR + 2) * (W + 2) + 64) * SBL_CP_PIXBV(sw);
     if (lds < (size_t)256 * SBL_CP_EROW * 4) lds = (size_t)256 * SBL_CP_EROW * 4;      // the epilogue's image of the tile
-    const int gx = ntiles < 256 ? ntiles : 256;      // persistent: one workgroup per CU (the patch takes most of its LDS)
+    const int cap = sw ? 512 : 256;      // persistent: one (two) workgroup(s) per CU
+    const int gx = ntiles < cap ? ntiles : cap;
     const dim3 grid(gx, Nout / 64);
     unsigned long long* stamp = sbl_next_stamp_slot(kid);
-#define SBL_CP_GO(P)                                                                                                           \
+#define SBL_CP_GO(P, S)                                                                                                        \
     do {                                                                                                                       \
-        static bool set_##P[64] = {false};                                                                                     \
+        static bool set_##P##S[64] = {false};                                                                                  \
         int dev = 0;                                                                                                           \
         if (hipGetDevice(&dev) != hipSuccess) return false;                                                                    \
-        if (!set_##P[dev & 63]) {                                                                                              \
-            if (hipFuncSetAttribute((const void*)sbl_conv_patch_kernel<P, DGRAD, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false; \
-            set_##P[dev & 63] = true;                                                                                          \
+        if (!set_##P##S[dev & 63]) {                                                                                           \
+            if (hipFuncSetAttribute((const void*)sbl_conv_patch_kernel<P, DGRAD, STATS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false; \
+            set_##P##S[dev & 63] = true;                                                                                       \
         }                                                                                                                      \
-        hipLaunchKernelGGL((sbl_conv_patch_kernel<P, DGRAD, STATS>), grid, dim3(256), lds, s, src, wk, epi, NIMG, H, W, C, Nout, TR, tpi, ntiles, stamp); \
+        hipLaunchKernelGGL((sbl_conv_patch_kernel<P, DGRAD, STATS, S>), grid, dim3(256), lds, s, src, wk, epi, NIMG, H, W, C, Nout, TR, tpi, ntiles, stamp); \
     } while (0)
-    if (g_sbl_prec == 6) SBL_CP_GO(6);
-    else if (g_sbl_prec == 3) SBL_CP_GO(3);
-    else SBL_CP_GO(1);
+    if (sw) {
+        if (g_sbl_prec == 6) SBL_CP_GO(6, true);
+        else if (g_sbl_prec == 3) SBL_CP_GO(3, true);
+        else SBL_CP_GO(1, true);
+    } else {
+        if (g_sbl_prec == 6) SBL_CP_GO(6, false);
+        else if (g_sbl_prec == 3) SBL_CP_GO(3, false);
+        else SBL_CP_GO(1, false);
+    }
 #undef SBL_CP_GO
     return true;
 }

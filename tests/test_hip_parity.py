@@ -241,6 +241,46 @@ def test_conv2d_fwd_dgrad_wgrad(ops, NIMG, H, W, Cin, Cout, k, stride):
     assert relerr(dw, 2 * w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("variant", [1, 0])
+def test_conv_patch_kernel_variants_agree(ops, variant):
+    """sbl_set_tuning knob 5: the shipped layer-1 kernel (2: swizzled 32-channel LDS rows) against the padded 64-channel
+    variant (1) and the per-tap gather kernels (0): forward with BN statistics and the fused input gradient, same inputs.
+    Variants 0 and 1 walk K in the same order (bit-identical); variant 2 walks it per 32-channel chunk (fp32 reordering)."""
+    NIMG, H, W, C = 9, 22, 22, 64
+    x = U("pv.x", (NIMG, H, W, C)).to(DEV)
+    w = U("pv.w", (C, C, 3, 3), 0.1).to(DEV)
+    dy = U("pv.dy", (NIMG, H, W, C)).to(DEV)
+    addend = U("pv.add", (NIMG, H, W, C)).to(DEV)
+    pre = U("pv.pre", (NIMG, H, W, C)).to(DEV)
+    mean, inv = U("pv.mu", (C,), 0.1).to(DEV), (U("pv.is", (C,), 0.2) + 1.0).to(DEV)
+    act = ((pre - mean) * inv).clamp_min(0).contiguous()
+    w_ohwi, w_dg = torch.empty(C, 3, 3, C, device=DEV), torch.empty(C, 3, 3, C, device=DEV)
+    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), C, C, 3, 3, None, 0, ops._s())
+    ws = ops._workspace()
+
+    def run(knob):
+        ops.call("sbl_set_tuning", 5, knob)
+        try:
+            y = torch.empty(NIMG, H, W, C, device=DEV)
+            stats = torch.zeros(2 * C, device=DEV, dtype=torch.float64)
+            ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), stats.data_ptr(), 1, NIMG, H, W, C, C, 3, 3, 1, 1,
+                     ws.data_ptr(), ops.WS_BYTES, ops._s())
+            dx = torch.empty_like(x)
+            sums = torch.zeros(2 * C, device=DEV, dtype=torch.float64)
+            ops.call("sbl_conv2d_dgrad_fused", dy.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), NIMG, H, W, C, C, 3, 3, 1, 1, ws.data_ptr(),
+                     ops.WS_BYTES, addend.data_ptr(), act.data_ptr(), pre.data_ptr(), mean.data_ptr(), inv.data_ptr(), None, None, None,
+                     sums.data_ptr(), 1, ops._s())
+            torch.cuda.synchronize()
+            return y, stats, dx, sums
+        finally:
+            ops.call("sbl_set_tuning", 5, 2)
+    ref = run(2)
+    got = run(variant)
+    tol = 4e-7 * (9 * C) ** 0.5 * 4
+    assert maxdiff(got[0], ref[0]) < tol and maxdiff(got[2], ref[2]) < tol
+    assert relerr(got[1], ref[1]) < 1e-5 and relerr(got[3], ref[3]) < 1e-5
+
+
 @pytest.mark.parametrize("NIMG,H,W,C,Cout", [(40, 22, 22, 64, 64), (20, 11, 11, 128, 128), (130, 6, 6, 256, 256), (150, 3, 3, 512, 512)])
 def test_dgrad_epilogue_reduces_the_next_batchnorm_backward(ops, NIMG, H, W, C, Cout):
     """sbl_conv2d_dgrad_bnstats: same dx as sbl_conv2d_dgrad (bit for bit) and the two per-channel sums that
