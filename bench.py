@@ -64,7 +64,7 @@ KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW,
                 6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)",
                 7: "sbl_wgrad_group_kernel<SegMC,SegMC 128x128> (all deferred decoder / encoder weight grads, one launch each, no split-K)",
                 8: "stem (Conv3d 5x7x7 fwd + BN/ReLU/pool + backward reduce + weight gradient; the two contractions follow the matmul precision)",
-                9: "attention_fwd/bwd_kernel (encoder self-attention and long cross-attention, one workgroup per (batch, head); fp32 MFMA)"}
+                9: "encoder self-attention (29 frames: two query tiles per (batch, head) on the one-wavefront attention_small kernels; config 5's 64 frames: attention_fwd/bwd_kernel, one workgroup per (batch, head)); fp32 MFMA"}
 # kernel-name patterns of each family in the rocprofv3 --pmc summary (profiles/*_pmc_fetch_write_per_kernel.csv)
 KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm2?_kernel<Dense[KM]C<64, \w+>, Dense[KM]C<64, \w+>, EpiStore",
                  3: r"sbl_mfma_gemm_kernel<Dense[KM]C<128, \w+>, Dense[KM]C<128, \w+>, EpiStore",

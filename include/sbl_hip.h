@@ -71,7 +71,8 @@ int sbl_get_matmul_precision(void);
  * knob 4: workgroup target of their split-K (default 1536; 0 = the general rule);
  * knob 5: patch-resident 3x3 / stride-1 convolution kernel for the large trunk maps: 2 (default) swizzled 32-channel LDS rows,
  *         two workgroups per CU; 1 padded 64-channel rows, one workgroup per CU; 0 the per-tap gather kernels;
- * knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile, default). */
+ * knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile, default);
+ * knob 7: position-major convolution weight gradients with Cout <= value on 64x64 tiles (default 512; 0 = 128x128 tiles). */
 int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear

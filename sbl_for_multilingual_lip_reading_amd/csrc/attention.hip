@@ -305,9 +305,11 @@ __device__ __forceinline__ void attention_small_fwd_body(const float* __restrict
                                                          float* __restrict__ o, long ldo, float* __restrict__ p_out,
                                                          int causal, int B, int H, const SegDesc& segs, int Lk_fixed,
                                                          float scale, uint32_t thresh, float keep_scale,
-                                                         const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+                                                         const uint64_t* __restrict__ seed, uint64_t offset, int nprob,
+                                                         unsigned long long* stamp = nullptr) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int prob = blockIdx.x * 4 + (threadIdx.x >> 6);
+    sbl_stamp_begin(stamp);      // (thread 0 = wavefront 0 of the workgroup, which always has a problem)
     if (prob >= nprob) return;   // whole wavefront; the kernel has no barrier
     const SmallProb P = small_prob(prob, B, H, segs, Lk_fixed);
     const int Lq = P.Lq, Lk = P.Lk;
@@ -388,15 +390,17 @@ __device__ __forceinline__ void attention_small_fwd_body(const float* __restrict
         const int i = 4 * g + r;
         if (i < Lq) *reinterpret_cast<float4*>(ob + (long)i * ldo + 4 * n) = make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
     }
+    sbl_stamp_end(stamp);
 }
 __global__ __launch_bounds__(256) void attention_small_fwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ k,
                                                                   long ldk, const float* __restrict__ v, long ldv,
                                                                   float* __restrict__ o, long ldo, float* __restrict__ p_out,
                                                                   int causal, int B, int H, SegDesc segs, int Lk_fixed,
                                                                   float scale, uint32_t thresh, float keep_scale,
-                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob,
+                                                                  unsigned long long* stamp) {
     attention_small_fwd_body(q, ldq, k, ldk, v, ldv, o, ldo, p_out, causal, B, H, segs, Lk_fixed, scale, thresh, keep_scale, seed, offset,
-                             nprob);
+                             nprob, stamp);
 }
 // Two same-shape problems in one launch (the two decoder directions; blockIdx.y picks the operand set).
 struct AttFwdSet {
@@ -427,8 +431,10 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
                                                                   float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
                                                                   float* __restrict__ dv, long lddv, int B, int H, SegDesc segs,
                                                                   int Lk_fixed, float scale, uint32_t thresh, float keep_scale,
-                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob) {
+                                                                  const uint64_t* __restrict__ seed, uint64_t offset, int nprob,
+                                                                  unsigned long long* stamp) {
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    sbl_stamp_begin(stamp);
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];      // SHARED_KV: [wavefront][dV | dK][32][64] partial tiles
     float* s_kv = s_dyn + (threadIdx.x >> 6) * 4096;                    // this wavefront's slice
     // SHARED_KV: wavefront w handles segments w, w + nw, ... of this (batch, head) one after the other and sums their dK / dV
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(SHARED_KV ? 512 : 256) void attention_small_bwd_ker
             *reinterpret_cast<float4*>(dst) = val;
         }
     }
+    sbl_stamp_end(stamp);
 }
 
 // Self-attention over 17..32 rows (the encoder's 29 frames): two query tiles of <= 16 rows per (batch, head), each a
@@ -702,7 +709,7 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
         const int nprob = nseg * B * H;
         hipLaunchKernelGGL(attention_small_fwd_kernel, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
                            ldv, o, ldo, p_out, mask_kind == 1, B, H, d, Lk_fixed, scale,
-                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob, (unsigned long long*)nullptr);
         SBL_LAUNCH_CHECK("sbl_attention_fwd(small)");
         return 0;
     }
@@ -712,7 +719,7 @@ extern "C" int sbl_attention_seg_fwd(const float* q, long ldq, const float* k, l
         const int nprob = 2 * B * H;
         hipLaunchKernelGGL(attention_small_fwd_kernel, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
                            ldv, o, ldo, p_out, mask_kind == 1, B, H, t, Lk, scale,
-                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob, sbl_next_stamp_slot(SBL_KID_ATTENTION));
         SBL_LAUNCH_CHECK("sbl_attention_fwd(query tiles)");
         return 0;
     }
@@ -782,11 +789,11 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
         if (shared_kv && Lk_fixed > 0 && nseg > 1)
             hipLaunchKernelGGL(attention_small_bwd_kernel<true>, dim3(B * H), dim3(64 * nwv), (size_t)nwv * 16384, (hipStream_t)stream, dout, lddo, q,
                                ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
-                               drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+                               drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob, (unsigned long long*)nullptr);
         else
             hipLaunchKernelGGL(attention_small_bwd_kernel<false>, dim3(sbl_cdiv(nprob, 4)), dim3(256), 0, (hipStream_t)stream, dout,
                                lddo, q, ldq, k, ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, d, Lk_fixed, scale,
-                               drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob);
+                               drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, nprob, (unsigned long long*)nullptr);
         SBL_LAUNCH_CHECK("sbl_attention_bwd(small)");
         return 0;
     }
@@ -797,7 +804,7 @@ extern "C" int sbl_attention_seg_bwd(const float* dout, long lddo, const float* 
         if (int e = at_attr((const void*)attention_small_bwd_kernel<true>, 8 * 16384, attr_set3)) return e;
         hipLaunchKernelGGL(attention_small_bwd_kernel<true>, dim3(B * H), dim3(128), (size_t)2 * 16384, (hipStream_t)stream, dout, lddo, q, ldq, k,
                            ldk, v, ldv, p, dq, lddq, dk, lddk, dv, lddv, B, H, t, Lk, scale,
-                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, 2 * B * H);
+                           drop_p > 0.f ? sbl_drop_thresh(drop_p) : 0u, 1.f / (1.f - drop_p), seed, offset, 2 * B * H, sbl_next_stamp_slot(SBL_KID_ATTENTION));
         SBL_LAUNCH_CHECK("sbl_attention_bwd(query tiles)");
         return 0;
     }

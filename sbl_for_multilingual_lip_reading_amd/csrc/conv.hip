@@ -6,6 +6,8 @@
 #include "mfma_gemm.h"
 #include "conv_patch.h"
 
+int g_sbl_pm_wg64_maxm = 512;    // knob 7: position-major weight gradients with Cout <= this on 64x64 tiles (0 = always 128x128; same-box step
+                                 // A/B 0 / 128 / 256 / 512: 32.33 / 32.32 / 32.33 / 32.20 ms)
 int g_sbl_conv_patch = 2;        // sbl_set_tuning knob 5: patch-resident 3x3 / stride-1 kernel for the large maps (conv_patch.h): 0 off,
                                  // 1 padded 64-channel rows (one workgroup per CU), 2 swizzled 32-channel rows (two per CU; default)
 int g_sbl_wg_s2_small = 1;      // sbl_set_tuning knob 3: stride-2 weight gradients on 64x64 tiles (128 -> 256: 459 -> 335 us, 256 -> 512: 447 -> 400 us)
@@ -372,7 +374,7 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
         EpiStore<2, false> e{dw, (long)N, nullptr, 0, nullptr, nullptr, 0};                                   \
         sbl_launch_gemm<DenseMC<BM, true>, ConvGatherMC<BN>, EpiStore<2, false>, BM, BN>(al, bl, e, M, N, K, splits, s, sc); \
     } while (0)
-    constexpr int pm_wg_tile = 128;
+    const int pm_wg_tile = (g_sbl_pm_wg64_maxm > 0 && M <= g_sbl_pm_wg64_maxm) ? 64 : 128;
     if (conv_pm_ok(Ho, Wo, KH, stride) && big && M >= 128 && Cin % 128 == 0) {
         // one tap per tile of the (tap, ci) axis: contract only over the pixels that tap can reach
 #define SBL_KPMW_(P) sbl_conv_pm_wgrad_kernel<DenseMCPM<T_>, ConvGatherMCPM<T_>, EpiStore<2, false>, T_, T_, P>
