@@ -69,10 +69,12 @@ int sbl_get_matmul_precision(void);
  * knob 2: largest tile count of a launch that takes the wave-group K split (default 320);
  * knob 3: stride-2 convolution weight gradients on 64x64 tiles (1, default) or by the general rule (0);
  * knob 4: workgroup target of their split-K (default 1536; 0 = the general rule);
- * knob 5: patch-resident 3x3 / stride-1 convolution kernel for the large trunk maps: 2 (default) swizzled 32-channel LDS rows,
+ * knob 5: patch-resident 3x3 / stride-1 convolution kernel for the 22x22 and 11x11 trunk maps: 2 (default) swizzled 32-channel LDS rows,
  *         two workgroups per CU; 1 padded 64-channel rows, one workgroup per CU; 0 the per-tap gather kernels;
  * knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile, default);
- * knob 7: position-major convolution weight gradients with Cout <= value on 64x64 tiles (default 512; 0 = 128x128 tiles). */
+ * knob 7: position-major convolution weight gradients with Cout <= value on 64x64 tiles (default 512; 0 = 128x128 tiles);
+ * knob 8: most images per tile of the patch-resident kernel (default 0 = as many as fit, i.e. two 11x11 maps; 1 = one,
+ *         which leaves the 11x11 layer on the position-major kernels). */
 int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear

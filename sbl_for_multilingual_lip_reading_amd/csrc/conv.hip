@@ -10,6 +10,7 @@ int g_sbl_pm_wg64_maxm = 512;    // knob 7: position-major weight gradients with
                                  // A/B 0 / 128 / 256 / 512: 32.33 / 32.32 / 32.33 / 32.20 ms)
 int g_sbl_conv_patch = 2;        // sbl_set_tuning knob 5: patch-resident 3x3 / stride-1 kernel for the large maps (conv_patch.h): 0 off,
                                  // 1 padded 64-channel rows (one workgroup per CU), 2 swizzled 32-channel rows (two per CU; default)
+int g_sbl_conv_patch_imgs = 0;   // knob 8: most images per tile of that kernel (0 = as many as fit: two 11x11 maps; 1 = single-image tiles only, i.e. layer 1 only)
 int g_sbl_wg_s2_small = 1;      // sbl_set_tuning knob 3: stride-2 weight gradients on 64x64 tiles (128 -> 256: 459 -> 335 us, 256 -> 512: 447 -> 400 us)
 int g_sbl_wg_target = 1536;     // knob 4: their workgroup target (0 = the default rule; same-box step A/B 32.44 / 32.34 / 32.29 ms for 128-tiles / 64-tiles / 64-tiles + 1536)
 static int check_conv(const char* who, int NIMG, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
@@ -64,8 +65,8 @@ extern "C" int sbl_conv2d_fwd(const float* x, const float* w, float* y, double* 
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
-    if (KH == 3 && stride == 1 && !conv_pm_ok(Ho, Wo, KH, stride)) {
-        // large maps (layer 1): the input patch of a tile staged once in LDS for all nine taps (conv_patch.h)
+    if (KH == 3 && stride == 1) {
+        // layers 1 and 2: the input patch of a tile staged once in LDS for all nine taps (conv_patch.h)
         bool done;
         const PatchEpi pe{y, stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (stats) done = sbl_launch_conv_patch<false, 1>(x, w, pe, NIMG, H, W, Cin, Cout, SBL_KID_CONV_FWD, s);
@@ -237,6 +238,18 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
     sbl_geom_finish(g);
     const long t128 = (long)sbl_cdiv(M, 128) * sbl_cdiv(N, 128);
     SBL_REQUIRE(!ws || (sbl_aligned16(ws) && ws_bytes >= (long)sizeof(int) * SBL_CONV_WS_COUNTERS), "sbl_conv2d_dgrad: workspace unaligned or < 16 KiB");
+    if (KH == 3 && stride == 1) {
+        // large maps: patch-resident kernel with mirrored taps (conv_patch.h); same epilogue functors
+        bool done;
+        const PatchEpi pe{dx, f.sums, f.addend, f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2};
+        if (f.sums) done = sbl_launch_conv_patch<true, 2>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
+        else if (f.addend) done = sbl_launch_conv_patch<true, 3>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
+        else done = sbl_launch_conv_patch<true, 0>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
+        if (done) {
+            SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(patch)");
+            return 0;
+        }
+    }
     if (conv_pm_ok(H, W, KH, stride)) {
 #define SBL_KPM_T_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, true, true>, BM_, BN_, true, P>
 #define SBL_KPM_A_(P) sbl_conv_pm_kernel<ConvGatherPM<BM_, true>, DenseKCTapList<BN_>, EpiStore<0, false, true>, BM_, BN_, true, P>
@@ -270,18 +283,6 @@ static int conv2d_dgrad_impl(const float* dy, const float* wt, float* dx, int NI
 #undef SBL_KPM_F_
         SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(pm)");
         return 0;
-    }
-    if (KH == 3 && stride == 1) {
-        // large maps: patch-resident kernel with mirrored taps (conv_patch.h); same epilogue functors
-        bool done;
-        const PatchEpi pe{dx, f.sums, f.addend, f.y, f.x, f.mean, f.inv, f.x2, f.mean2, f.inv2};
-        if (f.sums) done = sbl_launch_conv_patch<true, 2>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
-        else if (f.addend) done = sbl_launch_conv_patch<true, 3>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
-        else done = sbl_launch_conv_patch<true, 0>(dy, wt, pe, NIMG, H, W, Cout, Cin, SBL_KID_CONV_DGRAD, s);
-        if (done) {
-            SBL_LAUNCH_CHECK("sbl_conv2d_dgrad(patch)");
-            return 0;
-        }
     }
 #define SBL_CONV_DG(BM, BN, WN)                                                                               \
     do {                                                                                                      \

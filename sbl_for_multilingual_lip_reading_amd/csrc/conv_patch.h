@@ -57,7 +57,7 @@ struct PatchEpi {
 
 template <int NT, bool DGRAD, int STATS, bool SW>
 __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wk, PatchEpi epi,
-                                                             int NIMG, int H, int W, int C, int Nout, int TR, int tpi, int ntiles,
+                                                             int NIMG, int H, int W, int C, int Nout, int TR, int tpi, int ntiles, int G,
                                                              unsigned long long* stamp) {
     using Tm = BfTerms<NT>;
     constexpr int NPL = Tm::NPL;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
     sbl_stamp_begin(stamp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int PW = W + 2, PH = TR + 2;
-    const int plane = PH * PW * PIXB;
+    const int plane = G * PH * PW * PIXB;      // G > 1: the tile is G whole images (TR == H), each with its own halo
     unsigned char* wsm = cp_smem + NPL * plane;      // [plane][co 0..63][64 ci] of the current tap
     const int n0 = blockIdx.y * 64;
     const long M = (long)NIMG * H * W;
@@ -89,16 +89,17 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
     const int wrow = tid >> 2;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int img = tile / tpi, r0 = (tile - img * tpi) * TR;
-        const int rows = min(TR, H - r0), npix = rows * W;
+        const int img = (tile / tpi) * G, r0 = (tile - (tile / tpi) * tpi) * TR;
+        const int rows = min(TR, H - r0), gcount = min(G, NIMG - img), npix = gcount * rows * W;
         const long m0 = ((long)img * H + r0) * W;
         // this lane's two A-operand pixels (clamped: rows past the tile are computed and never stored)
         int arow[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = min((wave * 2 + i) * 32 + l31, npix - 1);
-            const int pr = p / W, pc = p - pr * W;
-            arow[i] = pr * PW + pc;
+            const int gi = p / (TR * W), rem = p - gi * (TR * W);      // (G == 1: gi = 0)
+            const int pr = rem / W, pc = rem - pr * W;
+            arow[i] = (gi * PH + pr) * PW + pc;
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
             __syncthreads();      // every wave is done reading the previous patch and weight block
             // ---- stage the patch chunk: (PH x PW) pixels x 64 channels, 16 float4 per pixel, zero halo; all of a thread's loads
             // are in flight before the first split
-            const int nq = PH * PW * Q4;
+            const int nq = G * PH * PW * Q4;
             constexpr int QB = 10;      // float4s per thread and batch (13 x 24 pixels x 8 float4 = 2496: one batch)
             for (int q0 = tid; q0 < nq; q0 += 256 * QB) {
                 float4 v[QB];
@@ -123,11 +124,12 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
                 for (int u = 0; u < QB; ++u) {
                     const int q = q0 + u * 256;
                     const int pix = q / Q4, c4 = (q % Q4) * 4;
-                    const int prow = pix / PW, pcol = pix - prow * PW;
+                    const int gi = pix / (PH * PW), rp = pix - gi * (PH * PW);
+                    const int prow = rp / PW, pcol = rp - prow * PW;
                     const int ih = r0 - 1 + prow, iw = pcol - 1;
-                    const bool ok = q < nq && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    const bool ok = q < nq && gi < gcount && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) v[u] = *reinterpret_cast<const float4*>(src + (((long)img * H + ih) * W + iw) * C + c0 + c4);
+                    if (ok) v[u] = *reinterpret_cast<const float4*>(src + (((long)(img + gi) * H + ih) * W + iw) * C + c0 + c4);
                 }
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
@@ -256,35 +258,46 @@ __global__ __launch_bounds__(256) void sbl_conv_patch_kernel(const float* __rest
     sbl_stamp_end(stamp);
 }
 
-// Tile rows for an H x W map: the largest TR <= H with TR * W <= 256 whose patch fits 160 KB of LDS at three planes
-// (0: the map does not take this path).
-static inline int sbl_conv_patch_rows(int H, int W, int nplanes, bool sw) {
+// Tile of an H x W map: TR rows of one image (G = 1; the largest TR with TR * W <= 256 whose patch fits the LDS budget, split
+// evenly over the image), or - small maps, whole images only - G images of H rows (G * H * W <= 256).  Returns false when
+// the map does not take this path (fewer than 7 of the tile's 8 row blocks would be used, or nothing fits).
+static inline bool sbl_conv_patch_tile(int H, int W, int nplanes, bool sw, int max_imgs, int& TR, int& G) {
+    const long budget = (sw ? 80 : 160) * 1024;
+    const int pixb = SBL_CP_PIXBV(sw);
     int best = 0;
     for (int tr = 1; tr <= H; ++tr)
-        if (tr * W <= 256 && ((long)(tr + 2) * (W + 2) + 64) * SBL_CP_PIXBV(sw) * nplanes <= (sw ? 80 : 160) * 1024) best = tr;
-    // prefer an even split of the image (22 rows: 11 + 11, not 11 + 11 with a ragged rest)
-    if (best > 0) {
-        const int parts = sbl_cdiv(H, best);
-        best = sbl_cdiv(H, parts);
+        if (tr * W <= 256 && ((long)(tr + 2) * (W + 2) + 64) * pixb * nplanes <= budget) best = tr;
+    if (best >= H) {      // a whole image fits: several per tile?
+        int g = 256 / (H * W);
+        if (max_imgs > 0 && g > max_imgs) g = max_imgs;
+        while (g > 1 && ((long)g * (H + 2) * (W + 2) + 64) * pixb * nplanes > budget) --g;
+        TR = H;
+        G = g < 1 ? 1 : g;
+        return G * H * W >= 224 || (G == 1 && H * W >= 160);
     }
-    return best;
+    if (best <= 0) return false;
+    const int parts = sbl_cdiv(H, best);      // an even split of the image (22 rows: 11 + 11)
+    TR = sbl_cdiv(H, parts);
+    G = 1;
+    return TR >= 4 && TR * W >= 160;
 }
 
-extern int g_sbl_conv_patch;      // sbl_set_tuning knob 5 (1 = on)
+extern int g_sbl_conv_patch, g_sbl_conv_patch_imgs;      // sbl_set_tuning knobs 5 and 8
 template <bool DGRAD, int STATS>
 static inline bool sbl_launch_conv_patch(const float* src, const float* wk, const PatchEpi& epi, int NIMG, int H, int W, int C, int Nout,
                                          int kid, hipStream_t s) {
     const bool sw = g_sbl_conv_patch == 2;      // knob 5: 1 = padded 64-channel rows (one workgroup per CU), 2 = swizzled 32-channel rows (two)
     if (!g_sbl_conv_patch || g_sbl_prec == 0 || C % 64 != 0 || Nout % 64 != 0) return false;
     const int npl = g_sbl_prec == 6 ? 3 : g_sbl_prec == 3 ? 2 : 1;
-    const int TR = sbl_conv_patch_rows(H, W, npl, sw);
-    if (TR < 4 || TR * W < 160) return false;      // small maps keep the position-major kernels (too few pixels per tile)
-    const int tpi = sbl_cdiv(H, TR), ntiles = NIMG * tpi;
-    size_t lds = (size_t)npl * ((TR + 2) * (W + 2) + 64) * SBL_CP_PIXBV(sw);
+    int TR = 0, G = 1;
+    if (!sbl_conv_patch_tile(H, W, npl, sw, g_sbl_conv_patch_imgs, TR, G)) return false;      // small maps keep the position-major kernels
+    const int tpi = sbl_cdiv(H, TR), ntiles = G > 1 ? sbl_cdiv(NIMG, G) : NIMG * tpi;
+    size_t lds = (size_t)npl * ((size_t)G * (TR + 2) * (W + 2) + 64) * SBL_CP_PIXBV(sw);
     if (lds < (size_t)256 * SBL_CP_EROW * 4) lds = (size_t)256 * SBL_CP_EROW * 4;      // the epilogue's image of the tile
     const int cap = sw ? 512 : 256;      // persistent: one (two) workgroup(s) per CU
-    const int gx = ntiles < cap ? ntiles : cap;
-    const dim3 grid(gx, Nout / 64);
+    const int gy = Nout / 64, capx = cap / gy > 0 ? cap / gy : 1;
+    const int gx = ntiles < capx ? ntiles : capx;
+    const dim3 grid(gx, gy);
     unsigned long long* stamp = sbl_next_stamp_slot(kid);
 #define SBL_CP_GO(P, S)                                                                                                        \
     do {                                                                                                                       \
@@ -295,7 +308,7 @@ static inline bool sbl_launch_conv_patch(const float* src, const float* wk, cons
             if (hipFuncSetAttribute((const void*)sbl_conv_patch_kernel<P, DGRAD, STATS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false; \
             set_##P##S[dev & 63] = true;                                                                                       \
         }                                                                                                                      \
-        hipLaunchKernelGGL((sbl_conv_patch_kernel<P, DGRAD, STATS, S>), grid, dim3(256), lds, s, src, wk, epi, NIMG, H, W, C, Nout, TR, tpi, ntiles, stamp); \
+        hipLaunchKernelGGL((sbl_conv_patch_kernel<P, DGRAD, STATS, S>), grid, dim3(256), lds, s, src, wk, epi, NIMG, H, W, C, Nout, TR, tpi, ntiles, G, stamp); \
     } while (0)
     if (sw) {
         if (g_sbl_prec == 6) SBL_CP_GO(6, true);

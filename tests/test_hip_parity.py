@@ -198,6 +198,8 @@ def _nhwc(t):
     (20, 22, 22, 128, 128, 3, 1),
     # patch-resident path (conv_patch.h) at config 5's 28x28 maps (4 tiles of 7 rows) and at a ragged split (20 rows: 10 + 10)
     (3, 28, 28, 64, 64, 3, 1), (2, 20, 24, 64, 128, 3, 1), (300, 22, 22, 64, 64, 3, 1),
+    # ... and at layer 2's 11x11 maps (two whole images per tile; odd image counts leave a one-image last tile)
+    (5, 11, 11, 128, 128, 3, 1), (601, 11, 11, 128, 128, 3, 1), (3, 10, 12, 128, 64, 3, 1),
     # position-major path (3x3 / stride 1, maps of <= 36 pixels): tiles inside one position, straddling two, covering many
     (150, 3, 3, 512, 512, 3, 1), (130, 6, 6, 256, 256, 3, 1), (70, 6, 6, 256, 256, 3, 1), (33, 4, 5, 256, 128, 3, 1),
     (9, 5, 4, 128, 256, 3, 1)])
@@ -241,12 +243,13 @@ def test_conv2d_fwd_dgrad_wgrad(ops, NIMG, H, W, Cin, Cout, k, stride):
     assert relerr(dw, 2 * w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(9, 22, 22, 64), (7, 11, 11, 128)])
 @pytest.mark.parametrize("variant", [1, 0])
-def test_conv_patch_kernel_variants_agree(ops, variant):
+def test_conv_patch_kernel_variants_agree(ops, variant, shape):
     """sbl_set_tuning knob 5: the shipped layer-1 kernel (2: swizzled 32-channel LDS rows) against the padded 64-channel
     variant (1) and the per-tap gather kernels (0): forward with BN statistics and the fused input gradient, same inputs.
     Variants 0 and 1 walk K in the same order (bit-identical); variant 2 walks it per 32-channel chunk (fp32 reordering)."""
-    NIMG, H, W, C = 9, 22, 22, 64
+    NIMG, H, W, C = shape
     x = U("pv.x", (NIMG, H, W, C)).to(DEV)
     w = U("pv.w", (C, C, 3, 3), 0.1).to(DEV)
     dy = U("pv.dy", (NIMG, H, W, C)).to(DEV)

@@ -1,5 +1,6 @@
 """patch-kernel variants (sbl_set_tuning knob 5: 0 per-tap gathers, 1 padded 64-channel rows, 2 swizzled 32-channel rows):
-agreement of forward / input gradient with variant 0 and the time of each alone (layer-1 shape)."""
+agreement of forward / input gradient with variant 0 and the time of each alone.
+usage: patch_variants.py [H C]   (default 22 64 = layer 1; 11 128 = layer 2, two images per tile)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -7,6 +8,8 @@ from sbl_for_multilingual_lip_reading_amd import ops
 dev = "cuda:0"
 ops.set_matmul_precision("bf16x6")
 NIMG, H, C = 928, 22, 64
+if len(sys.argv) > 2:
+    H, C = int(sys.argv[1]), int(sys.argv[2])
 x = torch.randn(NIMG, H, H, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05
 w_ohwi = torch.empty(C, 3, 3, C, device=dev); w_dg = torch.empty(C, 3, 3, C, device=dev)
 ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), C, C, 3, 3, None, 0, ops._s())
