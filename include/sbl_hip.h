@@ -74,7 +74,9 @@ int sbl_get_matmul_precision(void);
  * knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile, default);
  * knob 7: position-major convolution weight gradients with Cout <= value on 64x64 tiles (default 512; 0 = 128x128 tiles);
  * knob 8: most images per tile of the patch-resident kernel (default 0 = as many as fit, i.e. two 11x11 maps; 1 = one,
- *         which leaves the 11x11 layer on the position-major kernels). */
+ *         which leaves the 11x11 layer on the position-major kernels);
+ * knob 9: patch-resident weight gradient of the 3x3 / stride-1 convolutions for maps of at least `value` pixels (default 30:
+ *         the 22x22, 11x11 and 6x6 layers; 0 = the implicit-GEMM weight gradients everywhere). */
 int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear

@@ -5,11 +5,14 @@
 //   wgrad : dw[co, (tap,ci)]      = sum_{pix}    dy[pix, co] * x[gather(pix,tap), ci]         (split-K atomics)
 #include "mfma_gemm.h"
 #include "conv_patch.h"
+#include "conv_patch_wgrad.h"
 
 int g_sbl_pm_wg64_maxm = 512;    // knob 7: position-major weight gradients with Cout <= this on 64x64 tiles (0 = always 128x128; same-box step
                                  // A/B 0 / 128 / 256 / 512: 32.33 / 32.32 / 32.33 / 32.20 ms)
 int g_sbl_conv_patch = 2;        // sbl_set_tuning knob 5: patch-resident 3x3 / stride-1 kernel for the large maps (conv_patch.h): 0 off,
                                  // 1 padded 64-channel rows (one workgroup per CU), 2 swizzled 32-channel rows (two per CU; default)
+int g_sbl_conv_patch_wgrad = 30;  // knob 9: patch-resident weight gradient (conv_patch_wgrad.h) for 3x3 / stride-1 maps of at least this many pixels (0 = off;
+                                 // same-box step A/B 0 / 100 / 30: 32.22 / 31.84 / 31.73 ms)
 int g_sbl_conv_patch_imgs = 0;   // knob 8: most images per tile of that kernel (0 = as many as fit: two 11x11 maps; 1 = single-image tiles only, i.e. layer 1 only)
 int g_sbl_wg_s2_small = 1;      // sbl_set_tuning knob 3: stride-2 weight gradients on 64x64 tiles (128 -> 256: 459 -> 335 us, 256 -> 512: 447 -> 400 us)
 int g_sbl_wg_target = 1536;     // knob 4: their workgroup target (0 = the default rule; same-box step A/B 32.44 / 32.34 / 32.29 ms for 128-tiles / 64-tiles / 64-tiles + 1536)
@@ -364,6 +367,10 @@ extern "C" int sbl_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     const bool big = wg_tile ? wg_tile == 128 : (M >= 128 && N >= 1152 && !(stride == 2 && g_sbl_wg_s2_small));
     const int wg_target = wg_target_env ? wg_target_env : (g_sbl_wg_target > 0 && stride == 2 ? g_sbl_wg_target : (big ? 1536 : 3072));
     SplitCtl sc{nullptr, nullptr, nullptr, sbl_next_stamp_slot(SBL_KID_CONV_WGRAD)};
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && sbl_launch_conv_patch_wgrad(x, dy, dw, NIMG, H, W, Cin, Cout, sc.stamp, s)) {
+        SBL_LAUNCH_CHECK("sbl_conv2d_wgrad(patch)");
+        return 0;
+    }
 #define SBL_CONV_WG(BM, BN)                                                                                   \
     do {                                                                                                      \
         const long tiles = (long)sbl_cdiv(M, BM) * sbl_cdiv(N, BN);                                           \

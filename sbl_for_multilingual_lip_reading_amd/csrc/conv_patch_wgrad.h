@@ -27,6 +27,9 @@
 __device__ __forceinline__ int pwg_off(int row, int f) {      // byte offset of the 8-byte slot of channels 4f .. 4f + 3 of image row `row`
     return row * 128 + ((((f >> 1) ^ (((row >> 1) & 1) << 2))) << 4) + ((f & 1) << 3);
 }
+__device__ __forceinline__ int pwg_offc(int row, int fc) {      // the same with fc = 16 (f >> 1) + 8 (f & 1) precomputed
+    return ((row << 7) + fc) ^ ((row & 2) << 5);
+}
 __device__ __forceinline__ int pwg_div(int v, float r) { return (int)(((float)v + 0.5f) * r); }      // v / d for small v, r = 1 / d
 
 struct PwgGeom {
@@ -55,6 +58,21 @@ __global__ __launch_bounds__(SBL_PWG_THREADS) void sbl_conv_patch_wgrad_kernel(c
     const float* xsrc = x + jq * 64;
     const float* dsrc = dy + cq * 64;
     const int fA = 8 * cb + 4 * (g4 & 1) + p4, fB = 8 * jb + 4 * (g4 & 1) + p4;      // this lane's 8-byte slot of a row, per operand
+    const int fcB = ((fB >> 1) << 4) + ((fB & 1) << 3);
+    const int lrow = 8 * (g4 >> 1) + q4;                                              // its first pixel inside a 16-pixel step
+    const int doff0 = pwg_off(lrow, fA), doff1 = pwg_off(lrow + 4, fA);               // dy rows: step ks adds 16 rows = 2048 bytes
+    // pixel of a (full) tile -> patch row of its tap (0, 0): the same for every tile; rows past a short tile's pixels hold zeros
+    // in the dy image, so whatever patch row they name only has to exist
+    int* xtab = reinterpret_cast<int*>(pwg_smem + NPL * (xplane + dplane));
+    {
+        const int trw = gm.TR * gm.W;
+        for (int pix = tid; pix < gm.dyrows; pix += SBL_PWG_THREADS) {
+            const int pc = min(pix, gm.G * trw - 1);
+            const int gi = pwg_div(pc, gm.rTRW), rem = pc - gi * trw;
+            const int pr = pwg_div(rem, gm.rW), pcol = rem - pr * gm.W;
+            xtab[pix] = (gi * gm.PH + pr) * gm.PW + pcol;
+        }
+    }
 
     f32x16 acc[3];
 #pragma unroll
@@ -133,29 +151,20 @@ __global__ __launch_bounds__(SBL_PWG_THREADS) void sbl_conv_patch_wgrad_kernel(c
         __syncthreads();
         if (tile + (int)gridDim.x < gm.ntiles) fetch(tile + gridDim.x);      // in flight under this tile's MFMAs
         const int nks = (npix + 15) >> 4;
-        const int trw = gm.TR * gm.W;
         for (int ks = 0; ks < nks; ++ks) {
-            int drow[2], xrow[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int pk = ks * 16 + 8 * (g4 >> 1) + q4 + 4 * e;
-                drow[e] = pk;
-                const int pc = min(pk, npix - 1);
-                const int gi = pwg_div(pc, gm.rTRW), rem = pc - gi * trw;
-                const int pr = pwg_div(rem, gm.rW), pcol = rem - pr * gm.W;
-                xrow[e] = (gi * gm.PH + pr + kh) * gm.PW + pcol;
-            }
+            // this lane's two pixels of the step (rows 16 ks + 8 (g >> 1) + q, + 4): dy rows directly, patch rows through the table
+            const int xr0 = xtab[ks * 16 + lrow] + kh * gm.PW, xr1 = xtab[ks * 16 + lrow + 4] + kh * gm.PW;
             bf16x8 a[NPL];
 #pragma unroll
             for (int t = 0; t < NPL; ++t) {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(ds + t * dplane + pwg_off(drow[0], fA)));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(ds + t * dplane + pwg_off(drow[1], fA)));
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(ds + t * dplane + ks * 2048 + doff0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(ds + t * dplane + ks * 2048 + doff1));
                 a[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 bf16x8 b[NPL];
-                const int o0 = pwg_off(xrow[0] + kw, fB), o1 = pwg_off(xrow[1] + kw, fB);
+                const int o0 = pwg_offc(xr0 + kw, fcB), o1 = pwg_offc(xr1 + kw, fcB);
 #pragma unroll
                 for (int t = 0; t < NPL; ++t) {
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(xs + t * xplane + o0));
@@ -185,7 +194,7 @@ static inline bool sbl_conv_patch_wgrad_geom(int NIMG, int H, int W, int Cin, in
     const int PW = W + 4;
     auto fits = [&](int tr, int g) {
         const int xr = g * (tr + 2) * PW, px = g * tr * W, dr = (px + 15) / 16 * 16;
-        return xr <= max_xrows && px <= max_pix && (long)(xr + dr) * 128 * npl <= 160 * 1024;
+        return xr <= max_xrows && px <= max_pix && (long)(xr + dr) * 128 * npl + dr * 4 <= 160 * 1024;
     };
     int best = 0;
     for (int tr = 1; tr <= H; ++tr)
@@ -226,7 +235,7 @@ static inline bool sbl_launch_conv_patch_wgrad(const float* x, const float* dy, 
     int gx = 256 / combos;      // one workgroup per CU
     if (gx < 1) gx = 1;
     if (gx > gm.ntiles) gx = gm.ntiles;
-    const size_t lds = (size_t)npl * (gm.xrows + gm.dyrows) * 128;
+    const size_t lds = (size_t)npl * (gm.xrows + gm.dyrows) * 128 + (size_t)gm.dyrows * 4;      // images + pixel -> patch row table
 #define SBL_PWG_GO(P)                                                                                                          \
     do {                                                                                                                       \
         static bool set_##P[64] = {false};                                                                                     \

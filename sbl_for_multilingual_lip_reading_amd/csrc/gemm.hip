@@ -60,6 +60,12 @@ int g_sbl_ksplit_tiles = 320;      // knob 2 (same-box A/B of the whole step: 0 
 int g_sbl_big_min = 4096;          // knob 1
 extern "C" int sbl_set_tuning(int knob, int value) {
     extern int g_sbl_wg_s2_small, g_sbl_wg_target, g_sbl_conv_patch;
+    if (knob == 9) {
+        extern int g_sbl_conv_patch_wgrad;
+        SBL_REQUIRE(value >= 0, "sbl_set_tuning: negative value");
+        g_sbl_conv_patch_wgrad = value;
+        return 0;
+    }
     if (knob == 8) {
         extern int g_sbl_conv_patch_imgs;
         SBL_REQUIRE(value >= 0, "sbl_set_tuning: negative value");

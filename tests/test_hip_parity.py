@@ -284,6 +284,35 @@ def test_conv_patch_kernel_variants_agree(ops, variant, shape):
     assert relerr(got[1], ref[1]) < 1e-5 and relerr(got[3], ref[3]) < 1e-5
 
 
+@pytest.mark.parametrize("NIMG,H,W,Cin,Cout,knob", [
+    (9, 22, 22, 64, 64, 100), (7, 11, 11, 128, 128, 100), (10, 6, 6, 256, 128, 30), (5, 28, 28, 64, 128, 100), (4, 14, 14, 128, 64, 100),
+    (260, 11, 11, 64, 64, 100), (2, 9, 13, 64, 64, 100)])
+def test_conv_patch_weight_gradient_agrees_with_gather_kernels(ops, NIMG, H, W, Cin, Cout, knob):
+    """sbl_set_tuning knob 9: the patch-resident weight gradient (conv_patch_wgrad.h: pixel-major bf16 planes, transposed LDS
+    reads, one persistent workgroup per 64x64 channel block of all nine taps) against the implicit-GEMM weight gradients
+    (knob 9 = 0) and against torch in float64, including tiles of several images (6x6 at knob 30), ragged last tiles
+    (28 rows in tiles of 5), a partial last image group and more tiles than workgroups (260 images)."""
+    x = U("pw.x%d%d" % (H, Cin), (NIMG, Cin, H, W)).requires_grad_(False)
+    w = U("pw.w%d%d" % (Cout, Cin), (Cout, Cin, 3, 3), 0.1).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dy = U("pw.dy%d%d" % (NIMG, Cout), tuple(y.shape))
+    y.backward(dy.double())
+    xd, dyd = _nhwc(x).to(DEV), _nhwc(dy).to(DEV)
+
+    def run(k):
+        ops.call("sbl_set_tuning", 9, k)
+        try:
+            dwd = torch.empty(Cout, 3, 3, Cin, device=DEV)
+            ops.call("sbl_conv2d_wgrad", xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), NIMG, H, W, Cin, Cout, 3, 3, 1, 1, 0, ops._s())
+            torch.cuda.synchronize()
+            return dwd.permute(0, 3, 1, 2).contiguous()
+        finally:
+            ops.call("sbl_set_tuning", 9, 30)
+    got, ref = run(knob), run(0)
+    assert relerr(got, w.grad) < 2e-5 and relerr(ref, w.grad) < 2e-5
+    assert relerr(got, ref) < 2e-5
+
+
 @pytest.mark.parametrize("NIMG,H,W,C,Cout", [(40, 22, 22, 64, 64), (20, 11, 11, 128, 128), (130, 6, 6, 256, 256), (150, 3, 3, 512, 512)])
 def test_dgrad_epilogue_reduces_the_next_batchnorm_backward(ops, NIMG, H, W, C, Cout):
     """sbl_conv2d_dgrad_bnstats: same dx as sbl_conv2d_dgrad (bit for bit) and the two per-channel sums that
