@@ -59,18 +59,18 @@ MODE_DTYPE = {"f32": "f32", "bf16x6": "f32 (exact 3-way bf16 split, 6 bf16 MFMA 
 KERNEL_NAMES = {1: "sbl_skinny_gemm_kernel (decoder/encoder nn.Linear fwd/dX/dW, M<=512)",
                 2: "sbl_mfma_gemm_kernel / sbl_mfma_gemm2_kernel 64x64 dense (nn.Linear, M>512; gemm2 = both decoder directions per launch)",
                 3: "sbl_mfma_gemm_kernel 128x128 dense",
-                4: "sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (trunk conv fwd + BN stats)",
-                5: "sbl_mfma_gemm_kernel<ConvGatherKC dgrad,DenseKC> (trunk conv input grad)",
-                6: "sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (trunk conv weight grad, split-K atomics)",
+                4: "trunk conv fwd + BN stats: sbl_conv_patch_kernel (22x22, 11x11 maps), sbl_conv_pm_kernel (6x6, 3x3), sbl_mfma_gemm_kernel<ConvGatherKC,DenseKC> (stride 2, 1x1)",
+                5: "trunk conv input grad: sbl_conv_patch_kernel<dgrad> (22x22, 11x11), sbl_conv_pm_kernel<dgrad> (6x6, 3x3), sbl_conv_classes_kernel (stride 2: parity classes, one launch)",
+                6: "trunk conv weight grad: sbl_conv_patch_wgrad_kernel (3x3 stride 1 at 22x22, 11x11, 6x6), sbl_conv_pm_wgrad_kernel (3x3 maps), sbl_mfma_gemm_kernel<DenseMC,ConvGatherMC> (stride 2, 1x1; split-K atomics)",
                 7: "sbl_wgrad_group_kernel<SegMC,SegMC 128x128> (all deferred decoder / encoder weight grads, one launch each, no split-K)",
                 8: "stem (Conv3d 5x7x7 fwd + BN/ReLU/pool + backward reduce + weight gradient; the two contractions follow the matmul precision)",
                 9: "encoder self-attention (29 frames: two query tiles per (batch, head) on the one-wavefront attention_small kernels; config 5's 64 frames: attention_fwd/bwd_kernel, one workgroup per (batch, head)); fp32 MFMA"}
 # kernel-name patterns of each family in the rocprofv3 --pmc summary (profiles/*_pmc_fetch_write_per_kernel.csv)
 KERNEL_PMC_RE = {1: r"sbl_skinny_gemm_kernel", 2: r"sbl_mfma_gemm2?_kernel<Dense[KM]C<64, \w+>, Dense[KM]C<64, \w+>, EpiStore",
                  3: r"sbl_mfma_gemm_kernel<Dense[KM]C<128, \w+>, Dense[KM]C<128, \w+>, EpiStore",
-                 4: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, false>",
-                 5: r"(sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, true>",
-                 6: r"(sbl_mfma_gemm_kernel<DenseMC<\d+, true>, ConvGatherMC|sbl_conv_pm_wgrad_kernel)", 7: r"sbl_wgrad_group_kernel"}
+                 4: r"((sbl_mfma_gemm_kernel|sbl_conv_pm_kernel)<ConvGather(KC|PM)<\d+, false>|sbl_conv_patch_kernel<\d, false)",
+                 5: r"((sbl_mfma_gemm_kernel|sbl_conv_pm_kernel|sbl_conv_classes_kernel)<ConvGather(KC|PM)<\d+, true>|sbl_conv_patch_kernel<\d, true)",
+                 6: r"(sbl_mfma_gemm_kernel<DenseMC<\d+, true>, ConvGatherMC|sbl_conv_pm_wgrad_kernel|sbl_conv_patch_wgrad_kernel)", 7: r"sbl_wgrad_group_kernel"}
 PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_fetch_write_per_kernel.csv")
 T_START = time.perf_counter()
 
