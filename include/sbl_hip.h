@@ -76,7 +76,8 @@ int sbl_get_matmul_precision(void);
  * knob 8: most images per tile of the patch-resident kernel (default 0 = as many as fit, i.e. two 11x11 maps; 1 = one,
  *         which leaves the 11x11 layer on the position-major kernels);
  * knob 9: patch-resident weight gradient of the 3x3 / stride-1 convolutions for maps of at least `value` pixels (default 30:
- *         the 22x22, 11x11 and 6x6 layers; 0 = the implicit-GEMM weight gradients everywhere). */
+ *         the 22x22, 11x11 and 6x6 layers; 0 = the implicit-GEMM weight gradients everywhere);
+ * knob 10 / 11: workgroup target (default 256) and largest split count (default 8) of the in-launch split-K of sbl_gemm2_f32. */
 int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear

@@ -54,12 +54,18 @@ extern "C" int sbl_set_matmul_precision(int terms) {
     return 0;
 }
 extern "C" int sbl_get_matmul_precision(void) { return g_sbl_prec; }
+int g_sbl_gemm2_split_target = 256, g_sbl_gemm2_split_max = 8;      // knobs 10, 11: in-launch split-K of the two-direction decoder products
 int g_sbl_group_cap = 0;           // knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile)
 int g_sbl_wave_ksplit = 1;
 int g_sbl_ksplit_tiles = 320;      // knob 2 (same-box A/B of the whole step: 0 -> 32.99, 320 -> 32.81, 768 -> 32.99 ms)
 int g_sbl_big_min = 4096;          // knob 1
 extern "C" int sbl_set_tuning(int knob, int value) {
     extern int g_sbl_wg_s2_small, g_sbl_wg_target, g_sbl_conv_patch;
+    if (knob == 10 || knob == 11) {
+        SBL_REQUIRE(value >= 1, "sbl_set_tuning: value < 1");
+        (knob == 10 ? g_sbl_gemm2_split_target : g_sbl_gemm2_split_max) = value;
+        return 0;
+    }
     if (knob == 9) {
         extern int g_sbl_conv_patch_wgrad;
         SBL_REQUIRE(value >= 0, "sbl_set_tuning: negative value");
@@ -267,11 +273,11 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
     }
     int splits = 1;
     constexpr int split_tiles = 192;
-    constexpr int split_target = 256;
+    const int split_target = g_sbl_gemm2_split_target;
     if (2 * tiles64 < split_tiles && K >= 128) {
         splits = (int)((split_target + 2 * tiles64 - 1) / (2 * tiles64));
         if (splits > K / 64) splits = K / 64;
-        if (splits > 8) splits = 8;
+        if (splits > g_sbl_gemm2_split_max) splits = g_sbl_gemm2_split_max;
         if (splits < 1) splits = 1;
     }
     SplitCtl sc{nullptr, nullptr, nullptr, nullptr};
