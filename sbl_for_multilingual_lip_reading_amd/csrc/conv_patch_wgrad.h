@@ -232,7 +232,9 @@ static inline bool sbl_launch_conv_patch_wgrad(const float* x, const float* dy, 
     PwgGeom gm;
     if (!sbl_conv_patch_wgrad_geom(NIMG, H, W, Cin, Cout, npl, gm)) return false;
     const int combos = (Cin / 64) * (Cout / 64);
-    int gx = 256 / combos;      // one workgroup per CU
+    extern int g_sbl_exp[8];
+    const int cus = g_sbl_exp[0] > 0 ? g_sbl_exp[0] : 256;      // (experiment knob 100: leave CUs to the other stream)
+    int gx = cus / combos;      // one workgroup per CU
     if (gx < 1) gx = 1;
     if (gx > gm.ntiles) gx = gm.ntiles;
     const size_t lds = (size_t)npl * (gm.xrows + gm.dyrows) * 128 + (size_t)gm.dyrows * 4;      // images + pixel -> patch row table

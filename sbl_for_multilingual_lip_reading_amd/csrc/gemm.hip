@@ -54,6 +54,7 @@ extern "C" int sbl_set_matmul_precision(int terms) {
     return 0;
 }
 extern "C" int sbl_get_matmul_precision(void) { return g_sbl_prec; }
+int g_sbl_exp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 int g_sbl_gemm2_split_target = 256, g_sbl_gemm2_split_max = 8;      // knobs 10, 11: in-launch split-K of the two-direction decoder products
 int g_sbl_group_cap = 0;           // knob 6: cap on the workgroups of the grouped weight-gradient launch (0 = one per tile)
 int g_sbl_wave_ksplit = 1;
@@ -61,6 +62,20 @@ int g_sbl_ksplit_tiles = 320;      // knob 2 (same-box A/B of the whole step: 0 
 int g_sbl_big_min = 4096;          // knob 1
 extern "C" int sbl_set_tuning(int knob, int value) {
     extern int g_sbl_wg_s2_small, g_sbl_wg_target, g_sbl_conv_patch;
+    if (knob >= 100 && knob < 108) {      // scratch knobs for experiments (g_sbl_exp[knob - 100]); no shipped code path reads them unless DESIGN.md says so
+        g_sbl_exp[knob - 100] = value;
+        return 0;
+    }
+    if (knob == 13) {
+        extern int g_sbl_stem_ablate;
+        g_sbl_stem_ablate = value;
+        return 0;
+    }
+    if (knob == 12) {
+        extern int g_sbl_stem_wgrad_tr;
+        g_sbl_stem_wgrad_tr = value != 0;
+        return 0;
+    }
     if (knob == 10 || knob == 11) {
         SBL_REQUIRE(value >= 1, "sbl_set_tuning: value < 1");
         (knob == 10 ? g_sbl_gemm2_split_target : g_sbl_gemm2_split_max) = value;

@@ -699,6 +699,260 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     sbl_stamp_end(stamp);
 }
 
+// ------------------------------------------------------------------ backward pass 2, split-bf16 modes, operands split ONCE
+// The kernel above splits every operand where it is used: each dconv value in all four wavefronts, each patch value once per
+// tap it feeds (~60 times), 216 conversion instructions per 24 MFMAs.  Here both operands are split into bf16 planes on the
+// way INTO LDS and every MFMA operand comes out of two transposed reads (ds_read_b64_tr_b16: per 16 lanes a block of
+// 4 K-rows x 16 columns; each lane supplies the 8-byte-aligned address of 4 consecutive columns of one row):
+//  * A = dconv: pixel-major planes [64 pixels][64 co] (half a tile at a time: 4 pixel rows = 4 k-steps), 128-byte rows with
+//    the two 64-byte halves swapped on rows with bit 1 set (conflict-free for 4 consecutive rows).
+//  * B = taps: the columns of a block are taps; the 7 kw taps (+ 1 pad) of a (kt, kh) pair at pixel px are the 8 CONSECUTIVE
+//    patch values from column 2 px of patch row 2 py + kh, so a lane's "4 consecutive columns" are 4 consecutive patch
+//    values at element 2 px + {0, 4}: 8-byte aligned for even px.  Odd pixels read a second copy of the planes shifted by two
+//    elements.  A 32-column tile = 4 (kt, kh) pairs; 35 pairs -> 9 tiles (288 columns, 245 kept).
+// 6 wavefronts (co tile i, tap tiles j, j + 3, j + 6): 18 MFMAs per 6 + 18 transposed reads at bf16x6 and no conversion in the
+// K loop.  77 KB of LDS: two workgroups per CU.
+// MEASURED (tools/bench_stem.py, knob 12 / knob 13): 794 us against 801 us for the kernel above - not the default.  The phases
+// of a tile add up instead of overlapping: k-steps 300 us (LDS-bound: the tap reads are 2-way bank conflicts on the 80-byte
+// patch rows), dconv recompute 331 us (VALU-bound: ~300 instructions per (pixel, 4 channels) item for the pool / ReLU /
+// BatchNorm adjoint), patch staging 200 us (85 of them waiting for x); one workgroup per CU (grid 256) takes 813 us, two take
+// 835 us, starting the second half of the grid one phase late changes nothing.  What the split-per-use kernel spends on
+// conversions in its K loop this one spends on 12 % more MFMAs (9 tap tiles), LDS conflicts and a smaller overlap (2 x 6
+// wavefronts instead of 3 x 4).  Kept as a selectable variant and as the record of what the stem weight gradient is bound by:
+// the recompute, not the contraction.
+#define SW_RS 40                                   // patch row stride in elements (80 bytes: 8-byte aligned rows)
+#define SW_PLANE (ST_PT * ST_PH * SW_RS * 2)       // bytes of one patch plane (8400)
+#define SW_DPLANE (64 * 128)                       // bytes of one dconv plane (half tile)
+#define SW_THREADS 384
+#define SW_PQ 3                                      // patch quads per thread (5 * 21 * 10 = 1050 <= 3 * 384)
+__device__ __forceinline__ int sw_off(int row, int f) {      // 8-byte slot of channels 4f .. 4f + 3 of dconv row `row`
+    return row * 128 + ((((f >> 1) ^ (((row >> 1) & 1) << 2))) << 4) + ((f & 1) << 3);
+}
+template <int NT>
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void stem_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ conv,
+                                                                  const float* __restrict__ dpool, const uint8_t* __restrict__ argmax,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const double* __restrict__ sums, float* __restrict__ dw,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int T,
+                                                                  int H, int W, int Ho, int Wo, int Hp, int Wp, int TY, int TX,
+                                                                  int ntiles, unsigned long long* stamp, int ablate) {
+    using Tm = BfTerms<NT>;
+    constexpr int NPL = Tm::NPL;
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
+    sbl_stamp_begin(stamp);
+    unsigned char* pe = sw_smem;                              // patch planes, copy E then copy O (shifted by two elements)
+    unsigned char* dp = sw_smem + 2 * NPL * SW_PLANE;         // dconv planes of the current half tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int ci = wave & 1, cj = wave >> 1;                  // co tile, first tap tile (tiles cj, cj + 3, cj + 6)
+    const double cnt = (double)N * T * Ho * Wo;
+    if (blockIdx.x == 0 && tid < 64) {
+        dbeta[tid] = (float)sums[tid];
+        dgamma[tid] = (float)sums[64 + tid];
+    }
+    const int c4 = (tid & 15) * 4;
+    // per-channel constants of the BatchNorm adjoint in LDS (24 registers otherwise, live through the k-steps):
+    // [0] mean [1] invstd [2] gamma [3] beta [4] mean(g) [5] mean(g * xhat)
+    float* kc = reinterpret_cast<float*>(sw_smem + 2 * NPL * SW_PLANE + NPL * SW_DPLANE);
+    if (tid < 64) {
+        kc[0 * 64 + tid] = mean[tid];
+        kc[1 * 64 + tid] = invstd[tid];
+        kc[2 * 64 + tid] = gamma[tid];
+        kc[3 * 64 + tid] = beta[tid];
+        kc[4 * 64 + tid] = (float)(sums[tid] / cnt);
+        kc[5 * 64 + tid] = (float)(sums[64 + tid] / cnt);
+    }
+    // A operand: rows 16 s + 8 (g >> 1) + q (+ 4) of the half tile, channels 32 ci + 16 (g & 1) + 4 p
+    const int fA = 8 * ci + 4 * (g4 & 1) + p4;
+    const int aoff0 = sw_off(8 * (g4 >> 1) + q4, fA), aoff1 = sw_off(8 * (g4 >> 1) + q4 + 4, fA);      // step s adds 2048 bytes
+    // B operand: pixel px = 8 (g >> 1) + q (+ 4: 16 bytes further, same copy), columns 16 (g & 1) + 4 p .. + 3 of the tile =
+    // pair 4 tile + 2 (g & 1) + (p >> 1), kw = 4 (p & 1) .. + 3
+    int boff[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int pair = min(4 * (cj + 3 * u) + 2 * (g4 & 1) + (p4 >> 1), 34);      // pair 35 (pad) aliases 34: its columns are dropped
+        const int kt = pair / 7, kh = pair - kt * 7;
+        const int px = 8 * (g4 >> 1) + q4;
+        boff[u] = (q4 & 1) * (NPL * SW_PLANE) + ((kt * ST_PH + kh) * SW_RS + 2 * px + 4 * (p4 & 1) + 2 * (q4 & 1)) * 2;
+    }
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    // the tile's input patch as quads of 4 consecutive columns, all loads of a thread issued together (clamped addresses, the
+    // out-of-range values replaced by zeros afterwards: no branch around a load)
+    float4 pv[SW_PQ];
+    auto fetch_patch = [&](int tile) {
+        const int tx = tile % TX;
+        const int ty = (tile / TX) % TY;
+        const int img = tile / (TX * TY);
+        const int n = img / T, t = img - n * T;
+        const int ih0 = 2 * ty * ST_TH - 3, iw0 = 2 * tx * ST_TW - 3;
+#pragma unroll
+        for (int u = 0; u < SW_PQ; ++u) {
+            const int i = min(tid + u * SW_THREADS, ST_PT * ST_PH * (SW_RS / 4) - 1);
+            const int j = i % (SW_RS / 4);
+            const int r = (i / (SW_RS / 4)) % ST_PH;
+            const int f = i / (ST_PH * (SW_RS / 4));
+            const int tt = t + f - 2, ih = ih0 + r, iw = iw0 + 4 * j;
+            const bool rok = (unsigned)tt < (unsigned)T && (unsigned)ih < (unsigned)H;
+            const float* row = x + (((long)n * T + min(max(tt, 0), T - 1)) * H + min(max(ih, 0), H - 1)) * W;
+            const float a0 = row[min(max(iw + 0, 0), W - 1)], a1 = row[min(max(iw + 1, 0), W - 1)];
+            const float a2 = row[min(max(iw + 2, 0), W - 1)], a3 = row[min(max(iw + 3, 0), W - 1)];
+            pv[u].x = rok && (unsigned)(iw + 0) < (unsigned)W ? a0 : 0.f;
+            pv[u].y = rok && (unsigned)(iw + 1) < (unsigned)W ? a1 : 0.f;
+            pv[u].z = rok && (unsigned)(iw + 2) < (unsigned)W ? a2 : 0.f;
+            pv[u].w = rok && (unsigned)(iw + 3) < (unsigned)W ? a3 : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch_patch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % TX;
+        const int ty = (tile / TX) % TY;
+        const int img = tile / (TX * TY);
+        __syncthreads();      // every wavefront is done with the previous tile's planes
+        {   // patch registers (fetched under the previous tile's k-steps) -> planes; copy E at element 4 j, copy O at element 4 j + 2
+#pragma unroll
+            for (int u = 0; u < SW_PQ; ++u) {
+                const int i = tid + u * SW_THREADS;
+                if (i < ST_PT * ST_PH * (SW_RS / 4)) {
+                    const int j = i % (SW_RS / 4);
+                    uint2 pl[NPL];
+                    bf_split4<NPL>(pv[u], pl);
+                    const int eo = ((i / (SW_RS / 4)) * SW_RS + 4 * j) * 2;
+#pragma unroll
+                    for (int pq = 0; pq < NPL; ++pq) {
+                        *reinterpret_cast<uint2*>(pe + pq * SW_PLANE + eo) = pl[pq];
+                        *reinterpret_cast<unsigned*>(pe + (NPL + pq) * SW_PLANE + eo + 4) = pl[pq].x;
+                        // (the last quad of a row is padding - columns 36 .. 39, only 36 is data and copy O never reads it there)
+                        if (j < SW_RS / 4 - 1) *reinterpret_cast<unsigned*>(pe + (NPL + pq) * SW_PLANE + eo + 8) = pl[pq].y;
+                        if (j == 0) *reinterpret_cast<unsigned*>(pe + (NPL + pq) * SW_PLANE + eo) = 0u;      // elements 0, 1 of copy O: never data, kept finite
+                    }
+                }
+            }
+        }
+        if (tile + (int)gridDim.x < ntiles && !(ablate & 4)) fetch_patch(tile + gridDim.x);      // in flight under this tile's k-steps
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            if (hf) __syncthreads();      // the first half's k-steps are done with the dconv planes
+            // dconv of pixel rows 4 hf .. 4 hf + 3 -> planes; thread = (pixel, channel quad), up to three items per thread, the
+            // nine loads of an item (conv value, four pool candidates: arg-max bytes + pooled gradient) issued together and two
+            // items in flight
+            float4 cv[2], dq[2][4];
+            uint32_t am[2][4];
+            auto load_item = [&](int slot, int it) {
+                const int pix = min(it, 64 * 16 - 1) >> 4;
+                const int oh = min(ty * ST_TH + 4 * hf + (pix >> 4), Ho - 1), ow = min(tx * ST_TW + (pix & 15), Wo - 1);
+                cv[slot] = *reinterpret_cast<const float4*>(conv + (((long)img * Ho + oh) * Wo + ow) * 64 + c4);
+                const int ph0 = oh >> 1, pw0 = ow >> 1;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const long o = (((long)img * Hp + min(ph0 + a, Hp - 1)) * Wp + min(pw0 + b, Wp - 1)) * 64 + c4;
+                        am[slot][a * 2 + b] = *reinterpret_cast<const uint32_t*>(argmax + o);
+                        dq[slot][a * 2 + b] = *reinterpret_cast<const float4*>(dpool + o);
+                    }
+            };
+            auto apply_item = [&](int slot, int it) {
+                if (it < 64 * 16) {
+                    const int pix = it >> 4;
+                    const int oh = ty * ST_TH + 4 * hf + (pix >> 4), ow = tx * ST_TW + (pix & 15);
+                    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (oh < Ho && ow < Wo) {
+                        const float4 v = cv[slot];
+                        const float4 mu = *reinterpret_cast<const float4*>(kc + 0 * 64 + c4), is = *reinterpret_cast<const float4*>(kc + 1 * 64 + c4);
+                        const float4 ga = *reinterpret_cast<const float4*>(kc + 2 * 64 + c4), be = *reinterpret_cast<const float4*>(kc + 3 * 64 + c4);
+                        const float4 mg4 = *reinterpret_cast<const float4*>(kc + 4 * 64 + c4), mx4 = *reinterpret_cast<const float4*>(kc + 5 * 64 + c4);
+                        const float mg[4] = {mg4.x, mg4.y, mg4.z, mg4.w}, mgx[4] = {mx4.x, mx4.y, mx4.z, mx4.w};
+                        float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
+                        float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+                        // max-pool adjoint routed by the recorded arg-max (stem_gather_g's rule) times the ReLU mask
+                        float g[4] = {0.f, 0.f, 0.f, 0.f};
+                        const int ph0 = oh >> 1, pw0 = ow >> 1;
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                const int ph = min(ph0 + a, Hp - 1), pw = min(pw0 + b, Wp - 1);
+                                const bool valid = (a == 0 || ((oh & 1) && ph0 + 1 < Hp)) && (b == 0 || ((ow & 1) && pw0 + 1 < Wp));
+                                const int pos = (oh - 2 * ph + 1) * 3 + (ow - 2 * pw + 1);
+                                const uint32_t m = am[slot][a * 2 + b];
+                                const float4 dd = dq[slot][a * 2 + b];
+                                if (valid && (int)(m & 255) == pos) g[0] += dd.x;
+                                if (valid && (int)((m >> 8) & 255) == pos) g[1] += dd.y;
+                                if (valid && (int)((m >> 16) & 255) == pos) g[2] += dd.z;
+                                if (valid && (int)(m >> 24) == pos) g[3] += dd.w;
+                            }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (!(y[k] > 0.f)) g[k] = 0.f;
+                        d.x = ga.x * is.x * (g[0] - mg[0] - xh[0] * mgx[0]);
+                        d.y = ga.y * is.y * (g[1] - mg[1] - xh[1] * mgx[1]);
+                        d.z = ga.z * is.z * (g[2] - mg[2] - xh[2] * mgx[2]);
+                        d.w = ga.w * is.w * (g[3] - mg[3] - xh[3] * mgx[3]);
+                    }
+                    uint2 pl[NPL];
+                    bf_split4<NPL>(d, pl);
+                    const int off = sw_off(pix, tid & 15);
+#pragma unroll
+                    for (int pq = 0; pq < NPL; ++pq) *reinterpret_cast<uint2*>(dp + pq * SW_DPLANE + off) = pl[pq];
+                }
+            };
+#pragma unroll 1
+            for (int u = (ablate & 8) ? 3 : 0; u < 3; ++u) {      // (the third round covers 256 of the 384 threads)
+                if (!(ablate & 2)) load_item(0, tid + u * SW_THREADS);
+                apply_item(0, tid + u * SW_THREADS);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int sr = (ablate & 1) ? 4 : 0; sr < 4; ++sr) {          // k-step = pixel row 4 hf + sr of the tile
+                bf16x8 a[NPL];
+#pragma unroll
+                for (int pq = 0; pq < NPL; ++pq) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dp + pq * SW_DPLANE + sr * 2048 + aoff0));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dp + pq * SW_DPLANE + sr * 2048 + aoff1));
+                    a[pq] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+                const int rowb = (4 * hf + sr) * 2 * SW_RS * 2;      // patch row 2 py: bytes
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    bf16x8 b[NPL];
+#pragma unroll
+                    for (int pq = 0; pq < NPL; ++pq) {
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(pe + pq * SW_PLANE + rowb + boff[u]));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(pe + pq * SW_PLANE + rowb + boff[u] + 16));
+                        b[pq] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < Tm::N; ++tt) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[Tm::pa(tt)], b[Tm::pb(tt)], acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D: column l & 31 = (pair slot, kw) of the tap tile, row = co within the co tile
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int pair = 4 * (cj + 3 * u) + (l31 >> 3), kw = l31 & 7;
+        if (pair < 35 && kw < 7) {
+            const int k = pair * 7 + kw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dw + co * ST_K + k, acc[u][r]);
+            }
+        }
+    }
+    sbl_stamp_end(stamp);
+}
+int g_sbl_stem_ablate = 0;        // knob 13 (measurement only, WRONG RESULTS): stem_wgrad_tr_kernel without 1 the k-steps, 2 the dconv loads, 4 the patch loads, 8 the dconv phase
+int g_sbl_stem_wgrad_tr = 0;      // sbl_set_tuning knob 12: 1 = the kernel above, 0 = stem_wgrad_bf_kernel (default: 794 vs 801 us - see the comment above)
+
 // ------------------------------------------------------------------ host entry points
 static int stem_dims(const char* who, int N, int T, int H, int W) {
     SBL_REQUIRE(N > 0 && T > 0 && H >= 8 && W >= 8 && H % 4 == 0 && W % 4 == 0, "%s: bad clip dims N=%d T=%d H=%d W=%d (H,W multiples of 4)", who, N, T, H, W);
@@ -791,6 +1045,28 @@ extern "C" int sbl_stem_wgrad(const float* x, const float* conv_out, const float
     SBL_REQUIRE(ntiles < (1L << 31), "sbl_stem_wgrad: too many tiles");
     SBL_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 64 * ST_K, s));
     const int grid = (int)(ntiles < 768 ? ntiles : 768);   // 3 workgroups per CU (52 KB LDS each)
+    if (g_sbl_prec && g_sbl_stem_wgrad_tr) {
+        const int grid2 = (int)(ntiles < 512 ? ntiles : 512);   // 2 workgroups per CU (77 KB LDS each)
+#define SBL_SWT_(NT)                                                                                                           \
+    do {                                                                                                                       \
+        const size_t lds = 2 * BfTerms<NT>::NPL * SW_PLANE + BfTerms<NT>::NPL * SW_DPLANE + 6 * 64 * sizeof(float);                                   \
+        static bool set_[64] = {false};                                                                                        \
+        int dev = 0;                                                                                                           \
+        SBL_HIP(hipGetDevice(&dev));                                                                                           \
+        if (!set_[dev & 63]) {                                                                                                 \
+            SBL_HIP(hipFuncSetAttribute((const void*)stem_wgrad_tr_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+            set_[dev & 63] = true;                                                                                             \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(stem_wgrad_tr_kernel<NT>, dim3(grid2), dim3(SW_THREADS), lds, s, x, conv_out, dpooled, argmax, mean, invstd, gamma, \
+                           beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM), g_sbl_stem_ablate); \
+    } while (0)
+        if (g_sbl_prec == 6) SBL_SWT_(6);
+        else if (g_sbl_prec == 3) SBL_SWT_(3);
+        else SBL_SWT_(1);
+#undef SBL_SWT_
+        SBL_LAUNCH_CHECK("sbl_stem_wgrad(bf16, transposed reads)");
+        return 0;
+    }
     if (g_sbl_prec) {
 #define SBL_SWG_(NT) hipLaunchKernelGGL(stem_wgrad_bf_kernel<NT>, dim3(grid), dim3(256), 0, s, x, conv_out, dpooled, argmax, mean, invstd, gamma, \
                        beta, sums, dw, dgamma, dbeta, N, T, H, W, Ho, Wo, Ho / 2, Wo / 2, TY, TX, (int)ntiles, sbl_next_stamp_slot(SBL_KID_STEM))

@@ -402,6 +402,32 @@ def test_stem_reduced_precision_modes(mode, tol_out, tol_grad):
         assert float((a - r).norm() / r.norm()) < tol_grad
 
 
+@pytest.mark.parametrize("N,T,H,W", [(2, 3, 40, 56), (1, 4, 88, 88)])
+def test_stem_weight_gradient_kernels_agree(ops, N, T, H, W):
+    """sbl_set_tuning knob 12: the stem weight gradient with operands split once into LDS planes and transposed LDS reads
+    (knob 12 = 1; measured no faster, so not the default) against the split-per-use kernel, same inputs (the default is held
+    to the oracle by test_stem_fwd_bwd; this pins the
+    tap-column packing (35 (kt, kh) pairs x 8 columns, pad column and pad pair dropped) and the shifted plane copy for odd
+    pixels, including partial tiles: 20 x 28 and 44 x 44 output maps on 8 x 16 tiles)."""
+    x = torch.from_numpy(detfill.normal("stemk.x%d" % H, (N, T, H, W))).to(DEV)
+    w0 = U("stemk.w", (64, 1, 5, 7, 7), 0.08).to(DEV)
+    g0, b0 = (1 + 0.3 * U("stemk.g", (64,))).to(DEV), U("stemk.b", (64,), 0.2).to(DEV)
+    res = []
+    try:
+        for knob in (1, 0):
+            ops.call("sbl_set_tuning", 12, knob)
+            w, g, b = (t.clone().requires_grad_(True) for t in (w0, g0, b0))
+            rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+            out = ops.StemFn.apply(x, w, g, b, rm, rv, True, 0.1, 1e-5)
+            out.backward(U("stemk.dy%d" % H, tuple(out.shape)).to(DEV))
+            torch.cuda.synchronize()
+            res.append((w.grad.clone(), g.grad.clone(), b.grad.clone()))
+    finally:
+        ops.call("sbl_set_tuning", 12, 0)
+    assert relerr(res[0][0], res[1][0]) < 2e-5      # float atomics in a different order; a wrong column would be O(1)
+    assert maxdiff(res[0][1], res[1][1]) == 0 and maxdiff(res[0][2], res[1][2]) == 0
+
+
 def test_stem_pool_tie_break_on_constant_frames(ops):
     """An all-zero frame (the CLS config's padding frame) makes every conv output equal: ties everywhere.
     The pooled values and the weight gradient must still match torch's first-max rule."""

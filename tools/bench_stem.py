@@ -1,11 +1,15 @@
 """Stem kernels alone (Conv3d 5x7x7 forward + statistics, BN/ReLU/pool, backward reduce, weight gradient) at the bench clip
-size, per precision mode.  Usage: python tools/bench_stem.py [f32|bf16x6|bf16x3|bf16]..."""
+size, per precision mode.  Usage: python tools/bench_stem.py [--tuning KNOB=VALUE]... [f32|bf16x6|bf16x3|bf16]..."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sbl_for_multilingual_lip_reading_amd import ops
 dev = "cuda:0"
 N, T, H, W = 32, 29, 88, 88
+while len(sys.argv) > 2 and sys.argv[1] == "--tuning":      # sbl_set_tuning measurement knobs (include/sbl_hip.h)
+    k, v = sys.argv[2].split("=")
+    ops.call("sbl_set_tuning", int(k), int(v))
+    del sys.argv[1:3]
 
 
 def timeit(fn, n=10):
