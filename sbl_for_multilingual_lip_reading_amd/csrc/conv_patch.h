@@ -1,4 +1,5 @@
-// Patch-resident 3x3 / stride-1 convolution for the large trunk maps (ResNet layer 1: 22x22 x 64 channels), split-bf16 modes.
+// Patch-resident 3x3 / stride-1 convolution for the large trunk maps (ResNet layer 1: 22x22 x 64 channels, tiles of 11 rows;
+// layer 2: 11x11 x 128 channels, tiles of two whole images), split-bf16 modes.
 //
 // The implicit-GEMM kernels of mfma_gemm.h treat every tap as its own K range: each of the nine taps re-gathers its operand
 // from global memory and re-splits it into bf16 planes (9x the loads and conversions; 0.6-0.9 GB fetched per launch for

@@ -287,7 +287,7 @@ extern "C" int sbl_gemm2_f32(int M, int N, int K, const float* A0, const float* 
         }
     }
     int splits = 1;
-    constexpr int split_tiles = 192;
+    const int split_tiles = g_sbl_exp[1] > 0 ? g_sbl_exp[1] : 192;      // (experiment knob 101)
     const int split_target = g_sbl_gemm2_split_target;
     if (2 * tiles64 < split_tiles && K >= 128) {
         splits = (int)((split_target + 2 * tiles64 - 1) / (2 * tiles64));
