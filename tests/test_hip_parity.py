@@ -1707,6 +1707,37 @@ def test_full_size_properties(ops):
     assert maxdiff(p.sum(-1), torch.ones(256, 29)) < 1e-5
 
 
+@pytest.mark.parametrize("H,C", [(22, 64), (11, 128), (6, 256), (3, 512)])
+def test_full_size_trunk_conv_adjoint_identities(ops, H, C):
+    """The 3x3 / stride-1 trunk convolutions at BASELINE's full size (928 = 32 x 29 frames per launch; the patch-resident
+    forward / input-gradient / weight-gradient kernels on the 22x22, 11x11 and 6x6 maps, the position-major kernels on 3x3):
+    the three kernels are the three faces of one bilinear form, so  <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>
+    whatever the size - dot products in float64, no CPU reference."""
+    NIMG = 928
+    gen = torch.Generator(DEV).manual_seed(H * 1000 + C)
+    x = torch.randn(NIMG, H, H, C, device=DEV, generator=gen)
+    dy = torch.randn(NIMG, H, H, C, device=DEV, generator=gen)
+    w = torch.randn(C, C, 3, 3, device=DEV, generator=gen) * (1.0 / (3.0 * C ** 0.5))
+    w_ohwi, w_dg = torch.empty(C, 3, 3, C, device=DEV), torch.empty(C, 3, 3, C, device=DEV)
+    ops.call("sbl_conv_weight_pack", w.data_ptr(), w_ohwi.data_ptr(), w_dg.data_ptr(), C, C, 3, 3, None, 0, ops._s())
+    ws = ops._workspace()
+    y, dx, dw = torch.empty_like(x), torch.empty_like(x), torch.empty(C, 3, 3, C, device=DEV)
+    stats = torch.zeros(2 * C, device=DEV, dtype=torch.float64)
+    ops.call("sbl_conv2d_fwd", x.data_ptr(), w_ohwi.data_ptr(), y.data_ptr(), stats.data_ptr(), 1, NIMG, H, H, C, C, 3, 3, 1, 1,
+             ws.data_ptr(), ops.WS_BYTES, ops._s())
+    ops.call("sbl_conv2d_dgrad", dy.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), NIMG, H, H, C, C, 3, 3, 1, 1, ws.data_ptr(), ops.WS_BYTES, ops._s())
+    ops.call("sbl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), NIMG, H, H, C, C, 3, 3, 1, 1, 0, ops._s())
+    torch.cuda.synchronize()
+    a = float((y.double() * dy.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    c = float((w_ohwi.double() * dw.double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())      # |<y, dy>| <= scale; the three numbers are sums of ~1e8 products
+    assert abs(a - b) < 2e-6 * scale and abs(a - c) < 2e-6 * scale, (a, b, c, scale)
+    # the BatchNorm statistics of the forward epilogue against the tensor it wrote
+    yn = y.double().reshape(-1, C)
+    assert relerr(stats[:C], yn.sum(0)) < 1e-5 and relerr(stats[C:], (yn * yn).sum(0)) < 1e-5
+
+
 def test_full_size_step_properties(ops):
     """The whole 6+6 step at B=32, T=29, 88x88 (BASELINE config 3; the CPU oracle needs minutes there): properties that
     need no reference.  (1) the stage-batched, direction-merged decoder and the per-stage tape give the same loss and
