@@ -710,26 +710,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 //    patch values from column 2 px of patch row 2 py + kh, so a lane's "4 consecutive columns" are 4 consecutive patch
 //    values at element 2 px + {0, 4}: 8-byte aligned for even px.  Odd pixels read a second copy of the planes shifted by two
 //    elements.  A 32-column tile = 4 (kt, kh) pairs; 35 pairs -> 9 tiles (288 columns, 245 kept).
-// 6 wavefronts (co tile i, tap tiles j, j + 3, j + 6): 18 MFMAs per 6 + 18 transposed reads at bf16x6 and no conversion in the
-// K loop.  77 KB of LDS: two workgroups per CU.
-// MEASURED (tools/bench_stem.py, knob 12 / knob 13): 794 us against 801 us for the kernel above - not the default.  The phases
-// of a tile add up instead of overlapping: k-steps 300 us (LDS-bound: the tap reads are 2-way bank conflicts on the 80-byte
-// patch rows), dconv recompute 331 us (VALU-bound: ~300 instructions per (pixel, 4 channels) item for the pool / ReLU /
-// BatchNorm adjoint), patch staging 200 us (85 of them waiting for x); one workgroup per CU (grid 256) takes 813 us, two take
-// 835 us, starting the second half of the grid one phase late changes nothing.  What the split-per-use kernel spends on
-// conversions in its K loop this one spends on 12 % more MFMAs (9 tap tiles), LDS conflicts and a smaller overlap (2 x 6
-// wavefronts instead of 3 x 4).  Kept as a selectable variant and as the record of what the stem weight gradient is bound by:
-// the recompute, not the contraction.
+// 4 wavefronts: wavefront w owns tap tiles w and w + 4 for both co tiles and every other k-step of one co tile of the ninth
+// tap tile; 27 MFMAs per 12 + 15 transposed reads at bf16x6 (average) and no conversion in the K loop.  77 KB of LDS and
+// 4-wavefront workgroups: two per CU.
+// MEASURED (tools/bench_stem.py, knobs 12 / 13): 642 us against 801 us for the kernel above.  Phase ablation: k-steps 240 us
+// (MFMA-bound on the SIMDs of wavefronts 0 and 1: 30 MFMAs per k-step, 65 tiles per CU), dconv recompute 250 us (VALU: the
+// pool / ReLU / BatchNorm adjoint of 2048 (pixel, 4 channels) items per tile), patch staging 146 us - and the three still
+// ADD UP: a workgroup's phases are serial, and the second workgroup of the CU does not fill the other pipe (starting half of
+// the workgroups 0.5 - 2 us late changes nothing).  A first version with 6-wavefront workgroups (tap tiles j, j + 3, j + 6 per
+// wavefront) measured 794 us: two 6-wavefront workgroups do NOT co-reside on a CU even when registers and LDS allow it
+// (tools/probes/coresidency.hip: 4-wavefront workgroups do; the second workgroup's wavefronts are placed from SIMD 0 again,
+// 2 + 2 wavefronts of ~160 registers do not fit one SIMD), so that version ran one workgroup per CU.  Batching two recompute
+// items (48 more registers) spilled at 168 registers and took 1.2 ms.
 #define SW_RS 40                                   // patch row stride in elements (80 bytes: 8-byte aligned rows)
 #define SW_PLANE (ST_PT * ST_PH * SW_RS * 2)       // bytes of one patch plane (8400)
 #define SW_DPLANE (64 * 128)                       // bytes of one dconv plane (half tile)
-#define SW_THREADS 384
-#define SW_PQ 3                                      // patch quads per thread (5 * 21 * 10 = 1050 <= 3 * 384)
+#define SW_THREADS 256
+#define SW_PQ 5                                      // patch quads per thread (5 * 21 * 10 = 1050 <= 5 * 256)
 __device__ __forceinline__ int sw_off(int row, int f) {      // 8-byte slot of channels 4f .. 4f + 3 of dconv row `row`
     return row * 128 + ((((f >> 1) ^ (((row >> 1) & 1) << 2))) << 4) + ((f & 1) << 3);
 }
 template <int NT>
-__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void stem_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ conv,
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ conv,
                                                                   const float* __restrict__ dpool, const uint8_t* __restrict__ argmax,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -746,14 +748,13 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     unsigned char* dp = sw_smem + 2 * NPL * SW_PLANE;         // dconv planes of the current half tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int ci = wave & 1, cj = wave >> 1;                  // co tile, first tap tile (tiles cj, cj + 3, cj + 6)
     const double cnt = (double)N * T * Ho * Wo;
     if (blockIdx.x == 0 && tid < 64) {
         dbeta[tid] = (float)sums[tid];
         dgamma[tid] = (float)sums[64 + tid];
     }
     const int c4 = (tid & 15) * 4;
-    // per-channel constants of the BatchNorm adjoint in LDS (24 registers otherwise, live through the k-steps):
+    // per-channel constants of the BatchNorm adjoint in LDS:
     // [0] mean [1] invstd [2] gamma [3] beta [4] mean(g) [5] mean(g * xhat)
     float* kc = reinterpret_cast<float*>(sw_smem + 2 * NPL * SW_PLANE + NPL * SW_DPLANE);
     if (tid < 64) {
@@ -764,25 +765,35 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         kc[4 * 64 + tid] = (float)(sums[tid] / cnt);
         kc[5 * 64 + tid] = (float)(sums[64 + tid] / cnt);
     }
-    // A operand: rows 16 s + 8 (g >> 1) + q (+ 4) of the half tile, channels 32 ci + 16 (g & 1) + 4 p
-    const int fA = 8 * ci + 4 * (g4 & 1) + p4;
-    const int aoff0 = sw_off(8 * (g4 >> 1) + q4, fA), aoff1 = sw_off(8 * (g4 >> 1) + q4 + 4, fA);      // step s adds 2048 bytes
+    // Wavefront w: tap tiles w and w + 4 for both co tiles (4 accumulators); the ninth tap tile's two blocks are shared: co
+    // tile w & 1, the k-steps with (step & 1) == (w >> 1) - 27 MFMAs per k-step and wavefront on average at bf16x6.  4 wavefronts, not 6: two 6-wavefront workgroups do not
+    // co-reside on a CU (tools/probes/coresidency.hip: the second workgroup's wavefronts start at SIMD 0 again).
+    // A operand: rows 16 s + 8 (g >> 1) + q (+ 4) of the half tile, channels 32 i + 16 (g & 1) + 4 p
+    int aoff0[2], aoff1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int fA = 8 * i + 4 * (g4 & 1) + p4;
+        aoff0[i] = sw_off(8 * (g4 >> 1) + q4, fA);      // step s adds 2048 bytes
+        aoff1[i] = sw_off(8 * (g4 >> 1) + q4 + 4, fA);
+    }
     // B operand: pixel px = 8 (g >> 1) + q (+ 4: 16 bytes further, same copy), columns 16 (g & 1) + 4 p .. + 3 of the tile =
     // pair 4 tile + 2 (g & 1) + (p >> 1), kw = 4 (p & 1) .. + 3
     int boff[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        const int pair = min(4 * (cj + 3 * u) + 2 * (g4 & 1) + (p4 >> 1), 34);      // pair 35 (pad) aliases 34: its columns are dropped
+        const int tl = u < 2 ? wave + 4 * u : 8;
+        const int pair = min(4 * tl + 2 * (g4 & 1) + (p4 >> 1), 34);      // pair 35 (pad) aliases 34: its columns are dropped
         const int kt = pair / 7, kh = pair - kt * 7;
         const int px = 8 * (g4 >> 1) + q4;
         boff[u] = (q4 & 1) * (NPL * SW_PLANE) + ((kt * ST_PH + kh) * SW_RS + 2 * px + 4 * (p4 & 1) + 2 * (q4 & 1)) * 2;
     }
 
-    f32x16 acc[3];
+    f32x16 acc[2][2], accx;      // [tap tile slot][co tile], and the ninth tile's block
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+        acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
+        accx[r] = 0.f;
+    }
 
     // the tile's input patch as quads of 4 consecutive columns, all loads of a thread issued together (clamped addresses, the
     // out-of-range values replaced by zeros afterwards: no branch around a load)
@@ -841,10 +852,10 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int hf = 0; hf < 2; ++hf) {
             if (hf) __syncthreads();      // the first half's k-steps are done with the dconv planes
             // dconv of pixel rows 4 hf .. 4 hf + 3 -> planes; thread = (pixel, channel quad), up to three items per thread, the
-            // nine loads of an item (conv value, four pool candidates: arg-max bytes + pooled gradient) issued together and two
-            // items in flight
-            float4 cv[2], dq[2][4];
-            uint32_t am[2][4];
+            // nine loads of an item (conv value, four pool candidates: arg-max bytes + pooled gradient) issued together (two items in
+            // flight need 48 more registers: 67 spilled at the 168 the two-workgroup occupancy allows, 794 -> 1232 us)
+            float4 cv[1], dq[1][4];
+            uint32_t am[1][4];
             auto load_item = [&](int slot, int it) {
                 const int pix = min(it, 64 * 16 - 1) >> 4;
                 const int oh = min(ty * ST_TH + 4 * hf + (pix >> 4), Ho - 1), ow = min(tx * ST_TW + (pix & 15), Wo - 1);
@@ -905,53 +916,74 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
                 }
             };
 #pragma unroll 1
-            for (int u = (ablate & 8) ? 3 : 0; u < 3; ++u) {      // (the third round covers 256 of the 384 threads)
+            for (int u = (ablate & 8) ? 4 : 0; u < 4; ++u) {
                 if (!(ablate & 2)) load_item(0, tid + u * SW_THREADS);
                 apply_item(0, tid + u * SW_THREADS);
             }
             __syncthreads();
 #pragma unroll 1
             for (int sr = (ablate & 1) ? 4 : 0; sr < 4; ++sr) {          // k-step = pixel row 4 hf + sr of the tile
-                bf16x8 a[NPL];
+                bf16x8 a[2][NPL];
 #pragma unroll
-                for (int pq = 0; pq < NPL; ++pq) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dp + pq * SW_DPLANE + sr * 2048 + aoff0));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dp + pq * SW_DPLANE + sr * 2048 + aoff1));
-                    a[pq] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pq = 0; pq < NPL; ++pq) {
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dp + pq * SW_DPLANE + sr * 2048 + aoff0[i]));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(dp + pq * SW_DPLANE + sr * 2048 + aoff1[i]));
+                        a[i][pq] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
                 const int rowb = (4 * hf + sr) * 2 * SW_RS * 2;      // patch row 2 py: bytes
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    bf16x8 b[NPL];
+                auto tap_frag = [&](int u, bf16x8 (&b)[NPL]) {
 #pragma unroll
                     for (int pq = 0; pq < NPL; ++pq) {
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(pe + pq * SW_PLANE + rowb + boff[u]));
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(pe + pq * SW_PLANE + rowb + boff[u] + 16));
                         b[pq] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
+                };
 #pragma unroll
-                    for (int tt = 0; tt < Tm::N; ++tt) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[Tm::pa(tt)], b[Tm::pb(tt)], acc[u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 b[NPL];
+                    tap_frag(u, b);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int tt = 0; tt < Tm::N; ++tt)
+                            acc[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][Tm::pa(tt)], b[Tm::pb(tt)], acc[u][i], 0, 0, 0);
+                }
+                if ((sr & 1) == (wave >> 1)) {      // wavefront-uniform branch: every lane of the wavefront takes it (the transposed reads need a full EXEC)
+                    bf16x8 b[NPL];
+                    tap_frag(2, b);
+#pragma unroll
+                    for (int tt = 0; tt < Tm::N; ++tt) {
+                        if ((wave & 1) == 0) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][Tm::pa(tt)], b[Tm::pb(tt)], accx, 0, 0, 0);
+                        else accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][Tm::pa(tt)], b[Tm::pb(tt)], accx, 0, 0, 0);
+                    }
                 }
             }
         }
     }
     // D: column l & 31 = (pair slot, kw) of the tap tile, row = co within the co tile
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int pair = 4 * (cj + 3 * u) + (l31 >> 3), kw = l31 & 7;
+    auto flush = [&](const f32x16& v, int tl, int i) {
+        const int pair = 4 * tl + (l31 >> 3), kw = l31 & 7;
         if (pair < 35 && kw < 7) {
             const int k = pair * 7 + kw;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(dw + co * ST_K + k, acc[u][r]);
+                const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dw + co * ST_K + k, v[r]);
             }
         }
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) flush(acc[u][i], wave + 4 * u, i);
+    flush(accx, 8, wave & 1);      // (two wavefronts per co tile: partial sums over alternate k-steps)
     sbl_stamp_end(stamp);
 }
 int g_sbl_stem_ablate = 0;        // knob 13 (measurement only, WRONG RESULTS): stem_wgrad_tr_kernel without 1 the k-steps, 2 the dconv loads, 4 the patch loads, 8 the dconv phase
-int g_sbl_stem_wgrad_tr = 0;      // sbl_set_tuning knob 12: 1 = the kernel above, 0 = stem_wgrad_bf_kernel (default: 794 vs 801 us - see the comment above)
+int g_sbl_stem_wgrad_tr = 1;      // sbl_set_tuning knob 12: 1 = the kernel above (default), 0 = stem_wgrad_bf_kernel
 
 // ------------------------------------------------------------------ host entry points
 static int stem_dims(const char* who, int N, int T, int H, int W) {
