@@ -78,8 +78,8 @@ int sbl_get_matmul_precision(void);
  * knob 9: patch-resident weight gradient of the 3x3 / stride-1 convolutions for maps of at least `value` pixels (default 30:
  *         the 22x22, 11x11 and 6x6 layers; 0 = the implicit-GEMM weight gradients everywhere);
  * knob 10 / 11: workgroup target (default 256) and largest split count (default 8) of the in-launch split-K of sbl_gemm2_f32;
- * knob 12: stem weight gradient with operands split once into LDS planes and transposed LDS reads (1) or the
- *          split-per-use kernel (0, default: measured equal, 794 vs 801 us);
+ * knob 12: stem weight gradient with operands split once into LDS planes and transposed LDS reads (1, default: 635 us) or
+ *          the split-per-use kernel (0: 801 us);
  * knob 13: phase ablation of that variant (measurement only: results are WRONG while it is non-zero). */
 int sbl_set_tuning(int knob, int value);
 

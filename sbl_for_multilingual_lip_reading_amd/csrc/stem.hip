@@ -424,6 +424,46 @@ __device__ __forceinline__ void stem_gather_g(const float* __restrict__ dpool, c
         if (!(y[q] > 0.f)) g[q] = 0.f;
 }
 
+// The same in two halves, so that a caller can issue the loads of several pixels before the first use: the four pool
+// candidates' arg-max bytes and pooled gradients (clamped addresses), then the routing + ReLU mask.
+struct StemGather {
+    uint32_t am[4];
+    float4 d[4];
+};
+__device__ __forceinline__ void stem_gather_load(const float* __restrict__ dpool, const uint8_t* __restrict__ argmax, long img, int oh,
+                                                 int ow, int Hp, int Wp, int c4, StemGather& s) {
+    const int ph0 = oh >> 1, pw0 = ow >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const long o = ((img * Hp + min(ph0 + a, Hp - 1)) * Wp + min(pw0 + b, Wp - 1)) * 64 + c4;
+            s.am[a * 2 + b] = *reinterpret_cast<const uint32_t*>(argmax + o);
+            s.d[a * 2 + b] = *reinterpret_cast<const float4*>(dpool + o);
+        }
+}
+__device__ __forceinline__ void stem_gather_apply(const StemGather& s, int oh, int ow, int Hp, int Wp, const float y[4], float g[4]) {
+    g[0] = g[1] = g[2] = g[3] = 0.f;
+    const int ph0 = oh >> 1, pw0 = ow >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ph = min(ph0 + a, Hp - 1), pw = min(pw0 + b, Wp - 1);
+            const bool valid = (a == 0 || ((oh & 1) && ph0 + 1 < Hp)) && (b == 0 || ((ow & 1) && pw0 + 1 < Wp));
+            const int pos = (oh - 2 * ph + 1) * 3 + (ow - 2 * pw + 1);
+            const uint32_t am = s.am[a * 2 + b];
+            const float4 d = s.d[a * 2 + b];
+            if (valid && (int)(am & 255) == pos) g[0] += d.x;
+            if (valid && (int)((am >> 8) & 255) == pos) g[1] += d.y;
+            if (valid && (int)((am >> 16) & 255) == pos) g[2] += d.z;
+            if (valid && (int)(am >> 24) == pos) g[3] += d.w;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (!(y[q] > 0.f)) g[q] = 0.f;
+}
+
 // ------------------------------------------------------------------ backward pass 1: sum g, sum g*xhat
 __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const float* __restrict__ conv, const float* __restrict__ dpool,
                                                               const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
@@ -438,21 +478,47 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const float* __res
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
     const float4 be = *reinterpret_cast<const float4*>(beta + c4);
     float sg[4] = {0, 0, 0, 0}, sgx[4] = {0, 0, 0, 0};
-    const long npix = (long)NT * Ho * Wo;
-    for (long p = blockIdx.x * 16L + (threadIdx.x >> 4); p < npix; p += (long)gridDim.x * 16) {
-        const int ow = p % Wo;
-        const long q = p / Wo;
-        const int oh = q % Ho;
-        const long img = q / Ho;
-        const float4 v = *reinterpret_cast<const float4*>(conv + p * 64 + c4);
-        float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
-        float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
-        float g[4];
-        stem_gather_g(dpool, argmax, img, oh, ow, Hp, Wp, c4, y, g);
+    // a workgroup walks whole pixel rows (img, oh): one (scalar) division per row, 16 pixels x 16 channel quads per trip and
+    // SR_ROWS x SR_TRIPS trips in flight: all their loads (conv value + four pool candidates each) go out before the first
+    // use (one trip at a time: 249 us, three: 170 us; the traffic is 604 MB = 96 us)
+    constexpr int SR_TRIPS = 3, SR_ROWS = 1;      // (44-pixel rows: three trips of 16 pixels; two rows at a time need 197 registers: 187 us)
+    const int nrows = NT * Ho;
+    for (int r0 = blockIdx.x * SR_ROWS; r0 < nrows; r0 += gridDim.x * SR_ROWS) {
+        for (int ow0 = 0; ow0 < Wo; ow0 += 16 * SR_TRIPS) {
+            float4 v[SR_ROWS][SR_TRIPS];
+            StemGather sg_[SR_ROWS][SR_TRIPS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sg[k] += g[k];
-            sgx[k] += g[k] * xh[k];
+            for (int j = 0; j < SR_ROWS; ++j) {
+                const int r = min(r0 + j, nrows - 1);
+                const int img = r / Ho, oh = r - img * Ho;
+#pragma unroll
+                for (int u = 0; u < SR_TRIPS; ++u) {
+                    const int ow = min(ow0 + 16 * u + (int)(threadIdx.x >> 4), Wo - 1);
+                    v[j][u] = *reinterpret_cast<const float4*>(conv + ((long)r * Wo + ow) * 64 + c4);
+                    stem_gather_load(dpool, argmax, img, oh, ow, Hp, Wp, c4, sg_[j][u]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SR_ROWS; ++j) {
+                const int r = r0 + j;
+                const int img = r / Ho, oh = r - img * Ho;
+#pragma unroll
+                for (int u = 0; u < SR_TRIPS; ++u) {
+                    const int ow = ow0 + 16 * u + (int)(threadIdx.x >> 4);
+                    if (r < nrows && ow < Wo) {
+                        const float4 vv = v[j][u];
+                        float xh[4] = {(vv.x - mu.x) * is.x, (vv.y - mu.y) * is.y, (vv.z - mu.z) * is.z, (vv.w - mu.w) * is.w};
+                        float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+                        float g[4];
+                        stem_gather_apply(sg_[j][u], oh, ow, Hp, Wp, y, g);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            sg[k] += g[k];
+                            sgx[k] += g[k] * xh[k];
+                        }
+                    }
+                }
+            }
         }
     }
 #pragma unroll
