@@ -917,74 +917,77 @@ __global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             if (hf) __syncthreads();      // the first half's k-steps are done with the dconv planes
-            // dconv of pixel rows 4 hf .. 4 hf + 3 -> planes; thread = (pixel, channel quad), up to three items per thread, the
-            // nine loads of an item (conv value, four pool candidates: arg-max bytes + pooled gradient) issued together (two items in
-            // flight need 48 more registers: 67 spilled at the 168 the two-workgroup occupancy allows, 794 -> 1232 us)
-            float4 cv[1], dq[1][4];
-            uint32_t am[1][4];
-            auto load_item = [&](int slot, int it) {
-                const int pix = min(it, 64 * 16 - 1) >> 4;
-                const int oh = min(ty * ST_TH + 4 * hf + (pix >> 4), Ho - 1), ow = min(tx * ST_TW + (pix & 15), Wo - 1);
-                cv[slot] = *reinterpret_cast<const float4*>(conv + (((long)img * Ho + oh) * Wo + ow) * 64 + c4);
-                const int ph0 = oh >> 1, pw0 = ow >> 1;
+            // dconv of pixel rows 4 hf .. 4 hf + 3 -> planes.  Thread = (pixel column tid >> 4, channel quad tid & 15); item u of
+            // the thread is pixel row u of the half, so everything that depends on the column or the channels only is computed
+            // once per half: the column's two pool-window candidates (index, validity, position inside the window), the channel
+            // constants of the BatchNorm adjoint, the LDS slot.  The nine loads of an item (conv value, four pool candidates:
+            // arg-max bytes + pooled gradient) are issued together.
+            if (!(ablate & 8)) {
+                const int pcol = tid >> 4;
+                const int ow = tx * ST_TW + pcol, owc = min(ow, Wo - 1);
+                const int pw0 = owc >> 1;
+                const int pwb[2] = {min(pw0, Wp - 1), min(pw0 + 1, Wp - 1)};
+                const bool vb[2] = {true, (owc & 1) && pw0 + 1 < Wp};
+                const int posb[2] = {owc - 2 * pwb[0] + 1, owc - 2 * pwb[1] + 1};
+                const float4 mu = *reinterpret_cast<const float4*>(kc + 0 * 64 + c4), is = *reinterpret_cast<const float4*>(kc + 1 * 64 + c4);
+                const float4 ga = *reinterpret_cast<const float4*>(kc + 2 * 64 + c4), be = *reinterpret_cast<const float4*>(kc + 3 * 64 + c4);
+                const float4 mg = *reinterpret_cast<const float4*>(kc + 4 * 64 + c4), mgx = *reinterpret_cast<const float4*>(kc + 5 * 64 + c4);
+                const float4 gi = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
+#pragma unroll 1
+                for (int u = 0; u < 4; ++u) {
+                    const int oh = ty * ST_TH + 4 * hf + u, ohc = min(oh, Ho - 1);
+                    const int ph0 = ohc >> 1;
+                    const int pha[2] = {min(ph0, Hp - 1), min(ph0 + 1, Hp - 1)};
+                    const bool va[2] = {true, (ohc & 1) && ph0 + 1 < Hp};
+                    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f), dq[4];
+                    uint32_t am[4];
+                    if (!(ablate & 2)) {
+                        cv = *reinterpret_cast<const float4*>(conv + (((long)img * Ho + ohc) * Wo + owc) * 64 + c4);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                        for (int ca = 0; ca < 2; ++ca) {
+                            const long rowo = ((long)img * Hp + pha[ca]) * Wp;
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const long o = (((long)img * Hp + min(ph0 + a, Hp - 1)) * Wp + min(pw0 + b, Wp - 1)) * 64 + c4;
-                        am[slot][a * 2 + b] = *reinterpret_cast<const uint32_t*>(argmax + o);
-                        dq[slot][a * 2 + b] = *reinterpret_cast<const float4*>(dpool + o);
+                            for (int cb2 = 0; cb2 < 2; ++cb2) {
+                                const long o = (rowo + pwb[cb2]) * 64 + c4;
+                                am[ca * 2 + cb2] = *reinterpret_cast<const uint32_t*>(argmax + o);
+                                dq[ca * 2 + cb2] = *reinterpret_cast<const float4*>(dpool + o);
+                            }
+                        }
                     }
-            };
-            auto apply_item = [&](int slot, int it) {
-                if (it < 64 * 16) {
-                    const int pix = it >> 4;
-                    const int oh = ty * ST_TH + 4 * hf + (pix >> 4), ow = tx * ST_TW + (pix & 15);
                     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (oh < Ho && ow < Wo) {
-                        const float4 v = cv[slot];
-                        const float4 mu = *reinterpret_cast<const float4*>(kc + 0 * 64 + c4), is = *reinterpret_cast<const float4*>(kc + 1 * 64 + c4);
-                        const float4 ga = *reinterpret_cast<const float4*>(kc + 2 * 64 + c4), be = *reinterpret_cast<const float4*>(kc + 3 * 64 + c4);
-                        const float4 mg4 = *reinterpret_cast<const float4*>(kc + 4 * 64 + c4), mx4 = *reinterpret_cast<const float4*>(kc + 5 * 64 + c4);
-                        const float mg[4] = {mg4.x, mg4.y, mg4.z, mg4.w}, mgx[4] = {mx4.x, mx4.y, mx4.z, mx4.w};
-                        float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
-                        float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
+                        const float xh[4] = {(cv.x - mu.x) * is.x, (cv.y - mu.y) * is.y, (cv.z - mu.z) * is.z, (cv.w - mu.w) * is.w};
+                        const float y[4] = {xh[0] * ga.x + be.x, xh[1] * ga.y + be.y, xh[2] * ga.z + be.z, xh[3] * ga.w + be.w};
                         // max-pool adjoint routed by the recorded arg-max (stem_gather_g's rule) times the ReLU mask
                         float g[4] = {0.f, 0.f, 0.f, 0.f};
-                        const int ph0 = oh >> 1, pw0 = ow >> 1;
 #pragma unroll
-                        for (int a = 0; a < 2; ++a)
+                        for (int ca = 0; ca < 2; ++ca)
 #pragma unroll
-                            for (int b = 0; b < 2; ++b) {
-                                const int ph = min(ph0 + a, Hp - 1), pw = min(pw0 + b, Wp - 1);
-                                const bool valid = (a == 0 || ((oh & 1) && ph0 + 1 < Hp)) && (b == 0 || ((ow & 1) && pw0 + 1 < Wp));
-                                const int pos = (oh - 2 * ph + 1) * 3 + (ow - 2 * pw + 1);
-                                const uint32_t m = am[slot][a * 2 + b];
-                                const float4 dd = dq[slot][a * 2 + b];
-                                if (valid && (int)(m & 255) == pos) g[0] += dd.x;
-                                if (valid && (int)((m >> 8) & 255) == pos) g[1] += dd.y;
-                                if (valid && (int)((m >> 16) & 255) == pos) g[2] += dd.z;
-                                if (valid && (int)(m >> 24) == pos) g[3] += dd.w;
+                            for (int cb2 = 0; cb2 < 2; ++cb2) {
+                                // position of the pixel inside the candidate window, or 15 (no arg-max byte has that value) when the
+                                // candidate is not a window of this pixel
+                                const int pos = (va[ca] && vb[cb2]) ? (oh - 2 * pha[ca] + 1) * 3 + posb[cb2] : 15;
+                                const uint32_t m = am[ca * 2 + cb2];
+                                const float4 dd = dq[ca * 2 + cb2];
+                                if ((int)(m & 255) == pos) g[0] += dd.x;
+                                if ((int)((m >> 8) & 255) == pos) g[1] += dd.y;
+                                if ((int)((m >> 16) & 255) == pos) g[2] += dd.z;
+                                if ((int)(m >> 24) == pos) g[3] += dd.w;
                             }
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (!(y[k] > 0.f)) g[k] = 0.f;
-                        d.x = ga.x * is.x * (g[0] - mg[0] - xh[0] * mgx[0]);
-                        d.y = ga.y * is.y * (g[1] - mg[1] - xh[1] * mgx[1]);
-                        d.z = ga.z * is.z * (g[2] - mg[2] - xh[2] * mgx[2]);
-                        d.w = ga.w * is.w * (g[3] - mg[3] - xh[3] * mgx[3]);
+                        d.x = gi.x * (g[0] - mg.x - xh[0] * mgx.x);
+                        d.y = gi.y * (g[1] - mg.y - xh[1] * mgx.y);
+                        d.z = gi.z * (g[2] - mg.z - xh[2] * mgx.z);
+                        d.w = gi.w * (g[3] - mg.w - xh[3] * mgx.w);
                     }
                     uint2 pl[NPL];
                     bf_split4<NPL>(d, pl);
-                    const int off = sw_off(pix, tid & 15);
+                    const int off = sw_off(16 * u + pcol, tid & 15);
 #pragma unroll
                     for (int pq = 0; pq < NPL; ++pq) *reinterpret_cast<uint2*>(dp + pq * SW_DPLANE + off) = pl[pq];
                 }
-            };
-#pragma unroll 1
-            for (int u = (ablate & 8) ? 4 : 0; u < 4; ++u) {
-                if (!(ablate & 2)) load_item(0, tid + u * SW_THREADS);
-                apply_item(0, tid + u * SW_THREADS);
             }
             __syncthreads();
 #pragma unroll 1
