@@ -80,7 +80,9 @@ int sbl_get_matmul_precision(void);
  * knob 10 / 11: workgroup target (default 256) and largest split count (default 8) of the in-launch split-K of sbl_gemm2_f32;
  * knob 12: stem weight gradient with operands split once into LDS planes and transposed LDS reads (1, default: 635 us) or
  *          the split-per-use kernel (0: 801 us);
- * knob 13: phase ablation of that variant (measurement only: results are WRONG while it is non-zero). */
+ * knob 13: phase ablation of that variant (measurement only: results are WRONG while it is non-zero);
+ * knob 14: stem forward convolution with eight wavefronts (two tiles in flight) on one copy of the weight planes (1, default:
+ *          434 us) or the four-wavefront kernel (0: 497 us). */
 int sbl_set_tuning(int knob, int value);
 
 /* ---------------------------------------------------------------- dense GEMM / Linear

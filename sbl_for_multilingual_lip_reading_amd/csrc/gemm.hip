@@ -66,6 +66,11 @@ extern "C" int sbl_set_tuning(int knob, int value) {
         g_sbl_exp[knob - 100] = value;
         return 0;
     }
+    if (knob == 14) {
+        extern int g_sbl_stem_fwd8;
+        g_sbl_stem_fwd8 = value != 0;
+        return 0;
+    }
     if (knob == 13) {
         extern int g_sbl_stem_ablate;
         g_sbl_stem_ablate = value;

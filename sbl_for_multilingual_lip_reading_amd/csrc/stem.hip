@@ -163,6 +163,79 @@ __device__ __forceinline__ void sb_put_patch(float* patch, const float (&pre)[SB
         if (tid + u * 256 < SB_PATCH) patch[tid + u * 256] = pre[u];
 }
 
+// One tile of the contraction + epilogue for one wavefront (32 pixels x 64 channels): shared by the 4-wavefront kernel and the
+// 8-wavefront one below.
+template <int NT>
+__device__ __forceinline__ void sb_tile_compute(const float* patch, const unsigned char* wsm, int abase, int lane, int half, int l31,
+                                                int wave, int ty, int tx, int img, int Ho, int Wo, float* __restrict__ out,
+                                                float (&s1)[2], float (&s2)[2]) {
+    using Tm = BfTerms<NT>;
+    constexpr int NPL = Tm::NPL;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    // software pipeline over the 18 k-steps (one wave per SIMD: nothing else hides an LDS round trip): during the MFMAs of
+    // step j the wave splits the pixel floats of step j+1 (read during step j-1) and reads the weight fragments of step
+    // j+1 and the pixel floats of step j+2; scheduling groups spread that work through the MFMA shadows.
+    float2 raw[2][4];
+    bf16x8 a[2][NPL], b[2][2][NPL];
+    auto read_raw = [&](int j, float2 (&q)[4]) {
+        const float2* ap = reinterpret_cast<const float2*>(patch + abase + (half ? sb_rowoff(2 * j + 1) : sb_rowoff(2 * j)));
+        q[0] = ap[0]; q[1] = ap[1]; q[2] = ap[2]; q[3] = ap[3];
+    };
+    auto split_raw = [&](const float2 (&q)[4], bf16x8 (&f)[NPL]) {
+        uint2 lo[NPL], hi[NPL];
+        bf_split4<NPL>(make_float4(q[0].x, q[0].y, q[1].x, q[1].y), lo);
+        bf_split4<NPL>(make_float4(q[2].x, q[2].y, q[3].x, q[3].y), hi);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f[pl] = __builtin_bit_cast(bf16x8, make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y));
+    };
+    auto read_b = [&](int j, bf16x8 (&f)[2][NPL]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) f[c][pl] = *reinterpret_cast<const bf16x8*>(wsm + (((j * 2 + c) * NPL + pl) * 64 + lane) * 16);
+    };
+    read_raw(0, raw[0]);
+    read_b(0, b[0]);
+    read_raw(1, raw[1]);
+    split_raw(raw[0], a[0]);
+#pragma unroll
+    for (int j = 0; j < SB_KS; ++j) {
+        const int cur = j & 1, nxt = cur ^ 1;
+        if (j + 1 < SB_KS) {
+            read_b(j + 1, b[nxt]);
+            split_raw(raw[nxt], a[nxt]);
+        }
+        if (j + 2 < SB_KS) read_raw(j + 2, raw[cur]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < Tm::N; ++t) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][Tm::pa(t)], b[cur][c][Tm::pb(t)], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * Tm::N; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (12 * NPL + 6 + 2 * Tm::N - 1) / (2 * Tm::N), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    // D: col (lane&31) = channel, row = pixel (r&3) + 8*(r>>2) + 4*half of this wave's 32 pixels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int oh = ty * ST_TH + 2 * wave + (m >> 4), ow = tx * ST_TW + (m & 15);
+        if (oh < Ho && ow < Wo) {
+            float* o = out + (((long)img * Ho + oh) * Wo + ow) * 64 + l31;
+            o[0] = acc[0][r];
+            o[32] = acc[1][r];
+            s1[0] += acc[0][r];
+            s2[0] += acc[0][r] * acc[0][r];
+            s1[1] += acc[1][r];
+            s2[1] += acc[1][r] * acc[1][r];
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void stem_conv_fwd_bf_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                float* __restrict__ out, double* __restrict__ stats, int N,
@@ -210,69 +283,7 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_bf_kernel(const float* __re
         const int next = tile + (int)gridDim.x;
         if (next < ntiles) sb_fetch_patch(pre, x, next, TX, TY, T, H, W, tid);
 
-        f32x16 acc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
-        // software pipeline over the 18 k-steps (one wave per SIMD: nothing else hides an LDS round trip): during the MFMAs of
-        // step j the wave splits the pixel floats of step j+1 (read during step j-1) and reads the weight fragments of step
-        // j+1 and the pixel floats of step j+2; scheduling groups spread that work through the MFMA shadows.
-        float2 raw[2][4];
-        bf16x8 a[2][NPL], b[2][2][NPL];
-        auto read_raw = [&](int j, float2 (&q)[4]) {
-            const float2* ap = reinterpret_cast<const float2*>(patch + abase + (half ? sb_rowoff(2 * j + 1) : sb_rowoff(2 * j)));
-            q[0] = ap[0]; q[1] = ap[1]; q[2] = ap[2]; q[3] = ap[3];
-        };
-        auto split_raw = [&](const float2 (&q)[4], bf16x8 (&f)[NPL]) {
-            uint2 lo[NPL], hi[NPL];
-            bf_split4<NPL>(make_float4(q[0].x, q[0].y, q[1].x, q[1].y), lo);
-            bf_split4<NPL>(make_float4(q[2].x, q[2].y, q[3].x, q[3].y), hi);
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) f[pl] = __builtin_bit_cast(bf16x8, make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y));
-        };
-        auto read_b = [&](int j, bf16x8 (&f)[2][NPL]) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) f[c][pl] = *reinterpret_cast<const bf16x8*>(wsm + (((j * 2 + c) * NPL + pl) * 64 + lane) * 16);
-        };
-        read_raw(0, raw[0]);
-        read_b(0, b[0]);
-        read_raw(1, raw[1]);
-        split_raw(raw[0], a[0]);
-#pragma unroll
-        for (int j = 0; j < SB_KS; ++j) {
-            const int cur = j & 1, nxt = cur ^ 1;
-            if (j + 1 < SB_KS) {
-                read_b(j + 1, b[nxt]);
-                split_raw(raw[nxt], a[nxt]);
-            }
-            if (j + 2 < SB_KS) read_raw(j + 2, raw[cur]);
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int t = 0; t < Tm::N; ++t) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][Tm::pa(t)], b[cur][c][Tm::pb(t)], acc[c], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2 * Tm::N; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (12 * NPL + 6 + 2 * Tm::N - 1) / (2 * Tm::N), 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-        // D: col (lane&31) = channel, row = pixel (r&3) + 8*(r>>2) + 4*half of this wave's 32 pixels
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int oh = ty * ST_TH + 2 * wave + (m >> 4), ow = tx * ST_TW + (m & 15);
-            if (oh < Ho && ow < Wo) {
-                float* o = out + (((long)img * Ho + oh) * Wo + ow) * 64 + l31;
-                o[0] = acc[0][r];
-                o[32] = acc[1][r];
-                s1[0] += acc[0][r];
-                s2[0] += acc[0][r] * acc[0][r];
-                s1[1] += acc[1][r];
-                s2[1] += acc[1][r] * acc[1][r];
-            }
-        }
+        sb_tile_compute<NT>(patch, wsm, abase, lane, half, l31, wave, ty, tx, img, Ho, Wo, out, s1, s2);
         if (next < ntiles) sb_put_patch(patch0 + (cur ^ 1) * SB_PATCH, pre, tid);
         __syncthreads();       // next patch complete; every wave is done reading this one
         cur ^= 1;
@@ -297,13 +308,109 @@ template <int NT>
 static int stem_launch_fwd_bf(const float* x, const float* w, float* conv_out, double* stats, int N, int T, int H, int W, int Ho,
                               int Wo, int TY, int TX, int ntiles, hipStream_t s) {
     constexpr int lds = SB_KS * 2 * BfTerms<NT>::NPL * 1024 + 2 * SB_PATCH * 4;
-    static bool set = false;
-    if (!set) {
+    static bool set[64] = {false};
+    int dev = 0;
+    SBL_HIP(hipGetDevice(&dev));
+    if (!set[dev & 63]) {
         SBL_HIP(hipFuncSetAttribute((const void*)stem_conv_fwd_bf_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        set = true;
+        set[dev & 63] = true;
     }
     const int grid = ntiles < 256 ? ntiles : 256;          // persistent: one workgroup per CU
     hipLaunchKernelGGL(stem_conv_fwd_bf_kernel<NT>, dim3(grid), dim3(256), lds, s, x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX,
+                       ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
+    return 0;
+}
+
+// The same with EIGHT wavefronts on one copy of the weight planes: two groups of four wavefronts work on two tiles at a time
+// (each group with its own patch buffer), so every SIMD has two wavefronts whose conversion / LDS work and MFMAs interleave.
+// One patch buffer per group (two would not fit beside the 108 KB of weights): the next patch waits in registers and is
+// written between two workgroup barriers after both groups are done with the current one.
+template <int NT>
+__global__ __launch_bounds__(512) void stem_conv_fwd_bf2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ out, double* __restrict__ stats, int N,
+                                                                int T, int H, int W, int Ho, int Wo, int TY, int TX,
+                                                                int ntiles, unsigned long long* stamp) {
+    using Tm = BfTerms<NT>;
+    constexpr int NPL = Tm::NPL;
+    sbl_stamp_begin(stamp);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
+    unsigned char* wsm = sb_smem;                                              // SB_KS * 2 * NPL fragments of 1 KB
+    const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, lane = tid & 63, wave = gt >> 6, half = lane >> 5, l31 = lane & 31;
+    float* patch = reinterpret_cast<float*>(sb_smem + SB_KS * 2 * NPL * 1024) + grp * SB_PATCH;
+    for (int u = tid; u < SB_KS * 2 * 64; u += 512) {      // weights -> bf16 planes in fragment order (as above)
+        const int ln = u & 63, c = (u >> 6) & 1, j = u >> 7;
+        const int co = c * 32 + (ln & 31), r = 2 * j + (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (r < 35 && i < 7) ? w[co * ST_K + r * 7 + i] : 0.f;
+        uint2 lo[NPL], hi[NPL];
+        bf_split4<NPL>(make_float4(v[0], v[1], v[2], v[3]), lo);
+        bf_split4<NPL>(make_float4(v[4], v[5], v[6], v[7]), hi);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            *reinterpret_cast<uint4*>(wsm + (((j * 2 + c) * NPL + pl) * 64 + ln) * 16) = make_uint4(lo[pl].x, lo[pl].y, hi[pl].x, hi[pl].y);
+    }
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;      // this lane's A-operand pixel inside the tile
+    const int abase = py * 2 * ST_PWS + px * 2;
+    float pre[SB_PRE];
+    const int npairs = (ntiles + 1) >> 1;      // pair p = tiles 2p (group 0) and 2p + 1 (group 1); trip counts are workgroup-uniform
+    if ((int)blockIdx.x < npairs && (int)blockIdx.x * 2 + grp < ntiles) {
+        sb_fetch_patch(pre, x, blockIdx.x * 2 + grp, TX, TY, T, H, W, gt);
+        sb_put_patch(patch, pre, gt);
+    }
+    __syncthreads();
+    for (int pt = blockIdx.x; pt < npairs; pt += gridDim.x) {
+        const int tile = pt * 2 + grp;
+        const int npt = pt + (int)gridDim.x;
+        const bool nvalid = npt < npairs && npt * 2 + grp < ntiles;
+        if (nvalid) sb_fetch_patch(pre, x, npt * 2 + grp, TX, TY, T, H, W, gt);
+        if (tile < ntiles) {      // (uniform per group of four wavefronts)
+            const int tx = tile % TX;
+            const int ty = (tile / TX) % TY;
+            const int img = tile / (TX * TY);
+            sb_tile_compute<NT>(patch, wsm, abase, lane, half, l31, wave, ty, tx, img, Ho, Wo, out, s1, s2);
+        }
+        __syncthreads();       // both groups are done reading their patches
+        if (nvalid) sb_put_patch(patch, pre, gt);
+        __syncthreads();       // next patches complete
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32, 64);
+        s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    float (*red)[128] = reinterpret_cast<float (*)[128]>(sb_smem + SB_KS * 2 * NPL * 1024);      // the loop's last barrier retired every patch read
+    if (half == 0) {
+        red[tid >> 6][l31] = s1[0];
+        red[tid >> 6][32 + l31] = s1[1];
+        red[tid >> 6][64 + l31] = s2[0];
+        red[tid >> 6][96 + l31] = s2[1];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tid];
+        atomicAdd(stats + tid, (double)t);
+    }
+    sbl_stamp_end(stamp);
+}
+int g_sbl_stem_fwd8 = 1;      // sbl_set_tuning knob 14: 1 = the 8-wavefront forward kernel, 0 = the 4-wavefront one
+template <int NT>
+static int stem_launch_fwd_bf2(const float* x, const float* w, float* conv_out, double* stats, int N, int T, int H, int W, int Ho,
+                               int Wo, int TY, int TX, int ntiles, hipStream_t s) {
+    constexpr int lds = SB_KS * 2 * BfTerms<NT>::NPL * 1024 + 2 * SB_PATCH * 4;
+    static bool set[64] = {false};
+    int dev = 0;
+    SBL_HIP(hipGetDevice(&dev));
+    if (!set[dev & 63]) {
+        SBL_HIP(hipFuncSetAttribute((const void*)stem_conv_fwd_bf2_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        set[dev & 63] = true;
+    }
+    const int npairs = (ntiles + 1) / 2;
+    const int grid = npairs < 256 ? npairs : 256;          // persistent: one workgroup per CU
+    hipLaunchKernelGGL(stem_conv_fwd_bf2_kernel<NT>, dim3(grid), dim3(512), lds, s, x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX,
                        ntiles, sbl_next_stamp_slot(SBL_KID_STEM));
     return 0;
 }
@@ -1071,7 +1178,13 @@ extern "C" int sbl_stem_conv_fwd(const float* x, const float* w, float* conv_out
     SBL_REQUIRE(ntiles < (1L << 31), "sbl_stem_conv_fwd: too many tiles");
     SBL_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 128, s));
     if (g_sbl_prec) {
-        int e = g_sbl_prec == 6 ? stem_launch_fwd_bf<6>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
+        int e;
+        if (g_sbl_stem_fwd8)
+            e = g_sbl_prec == 6 ? stem_launch_fwd_bf2<6>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
+              : g_sbl_prec == 3 ? stem_launch_fwd_bf2<3>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
+                                : stem_launch_fwd_bf2<1>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s);
+        else
+            e = g_sbl_prec == 6 ? stem_launch_fwd_bf<6>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
               : g_sbl_prec == 3 ? stem_launch_fwd_bf<3>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s)
                                 : stem_launch_fwd_bf<1>(x, w, conv_out, stats, N, T, H, W, Ho, Wo, TY, TX, (int)ntiles, s);
         if (e) return e;
