@@ -10,7 +10,7 @@ rm -rf $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 bench.py --no-cpu-baseline --no-kernel-timing --no-f32-exact --steps 8 --warmup 3 "$@" > gpurun_out/${tag}_bench.log 2>&1
 trace=$(find $out -name "*kernel_trace.csv" | head -1)
 stats=$(find $out -name "*kernel_stats.csv" | head -1)
-python3 tools/trace_report.py "$trace" -3 16 > gpurun_out/${tag}_timeline.txt
+python3 tools/trace_report.py "$trace" median 16 > gpurun_out/${tag}_timeline.txt
 cp "$stats" gpurun_out/${tag}_kernel_stats.csv
 rm -rf $out
 tail -1 gpurun_out/${tag}_bench.log | cut -c1-200

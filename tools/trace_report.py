@@ -3,7 +3,15 @@ import csv, collections, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'stem_conv_fwd' in r['Kernel_Name']]
-which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+if len(sys.argv) > 2 and sys.argv[2] == "median":
+    # among the last 16 complete steps (bench.py replays every coin pattern twice at the end) the one whose kernel count is
+    # closest to the middle of their range: a step with the expected number of own-arg-max coins
+    cand = list(range(max(0, len(idx) - 17), len(idx) - 1))
+    cnts = [idx[j + 1] - idx[j] for j in cand]
+    mean = (min(cnts) + max(cnts)) / 2.0      # mid-range: the stratified patterns are symmetric about the expectation
+    which = min(cand, key=lambda j: (abs(idx[j + 1] - idx[j] - mean), -j)) - len(idx)
+else:
+    which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
 a, b = idx[which], idx[which + 1]
 step = rows[a:b]
 t0 = int(step[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in step)
